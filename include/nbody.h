@@ -1,0 +1,138 @@
+/*
+ * nbody.h -- C ABI of the MI355X-native all-pairs N-body step (libnbody_amd.so).
+ *
+ * Drop-in boundary for ONE path of ctbfl/N_body_problem: the per-frame "step" bracket of
+ * main_project/kernel.cu:1225-1242 (map the position VBO, run the force + update kernels,
+ * synchronise, unmap) together with the buffer set-up that feeds it (kernel.cu:130-188).
+ * File:line citations below are relative to the reference's main_project/.
+ *
+ * Buffer layout (the reference's OpenGL-interop layout, kernel.cu:139-158, 1168-1171):
+ *   positions  : n x float4 {x, y, z, mass}, 16-byte aligned, updated IN PLACE by a step
+ *                (a renderer may read it between steps, as GL does at kernel.cu:1259-1261);
+ *   velocities : n x float4 {vx, vy, vz, w}; .w (the per-particle eps the reference loads at
+ *                kernel.cu:223 and never reads) is preserved untouched.
+ * All device pointers are plain HIP device addresses on the context's device.  No GL objects:
+ * cudaGraphicsResourceGetMappedPointer (kernel.cu:1226) becomes "the caller passes a pointer".
+ *
+ * Every entry point returns NBODY_OK (0) or a negative nbody_status; nothing throws, nothing
+ * prints.  The message of the last failure is kept per context (nbody_last_error).
+ * A context is not thread-safe (the reference drives everything from one host thread).
+ *
+ * Numerics: fp32 storage and pair arithmetic; r^2 + eps^2 by an FMA chain; v_rsq_f32; each
+ * row's sum over columns runs in ascending column order inside fixed-length column "splits",
+ * and the per-split partial sums are added in ascending split order by the update kernel, so
+ * results are bit-identical for any sharding of rows or columns that respects split_len.
+ * Update: v <- (float)fma((double)a,(double)dt,(double)v); x <- (float)fma((double)v,(double)dt,(double)x)
+ * (kernel.cu:777-801 with TIME_TICK -> dt).
+ */
+#ifndef NBODY_AMD_H
+#define NBODY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_ABI_VERSION 1
+
+typedef struct nbody_ctx nbody_ctx;
+
+typedef enum nbody_status {
+    NBODY_OK = 0,
+    NBODY_ERR_INVALID = -1,   /* bad argument (NULL, negative size, misaligned range) */
+    NBODY_ERR_ALLOC = -2,     /* device or host allocation failed (kernel.cu:1151-1160 returns -1) */
+    NBODY_ERR_DEVICE = -3,    /* a HIP call or kernel failed (kernel.cu:1238-1241 prints and continues) */
+    NBODY_ERR_NO_DEVICE = -4, /* no usable gfx950 device: there is no CPU fallback */
+    NBODY_ERR_STATE = -5      /* call needs context-owned buffers that were never uploaded */
+} nbody_status;
+
+int nbody_abi_version(void);
+const char *nbody_status_string(int status);
+
+/* ---- context: replaces initialize(numBodies), kernel.cu:130-161, and the scratch set-up at :1148-1160 ----
+ * nbody_create      : all n_total bodies are rows and columns of this context (one GPU).
+ * nbody_create_shard: the context integrates rows [row_lo, row_lo+row_count) against all n_total
+ *                     columns (one rank of a multi-GPU run).  split_len = columns per partial sum,
+ *                     a multiple of 256, 0 = nbody_default_split_len(n_total); row_lo must be a
+ *                     multiple of split_len so that shard boundaries never cut a split.
+ * The context owns the acceleration partials (the reference's gravity_sum_array), a stream and, on
+ * demand, position/velocity buffers.  n_total need not be padded; the reference's roundup(n,256)+1
+ * zero-mass padding (kernel.cu:260-278) is accepted and leaves real bodies' results unchanged. */
+int nbody_create(nbody_ctx **out, int device, int64_t n_total);
+int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row_lo, int64_t row_count,
+                       int64_t split_len);
+int nbody_destroy(nbody_ctx *ctx);
+const char *nbody_last_error(const nbody_ctx *ctx); /* ctx == NULL: last error of a failed create */
+int64_t nbody_default_split_len(int64_t n_total);
+int64_t nbody_split_len(const nbody_ctx *ctx);
+int64_t nbody_n_total(const nbody_ctx *ctx);
+
+/* ---- context-owned buffers: setParticlesPosition / setParticlesVelocity, kernel.cu:163-188 ----
+ * Host arrays of n_total float4 (positions) and row_count float4 (velocities of this context's rows).
+ * Allocates the device buffers on first use.  nbody_download copies back; either pointer may be NULL. */
+int nbody_set_positions(nbody_ctx *ctx, const float *host_xyzm);
+int nbody_set_velocities(nbody_ctx *ctx, const float *host_xyzw);
+int nbody_download(nbody_ctx *ctx, float *host_xyzm, float *host_xyzw);
+/* Device addresses of the owned buffers (NULL before the first set_*): the mapped-pointer analogue
+ * of cudaGraphicsResourceGetMappedPointer, kernel.cu:1226. */
+float *nbody_positions_device(nbody_ctx *ctx);
+float *nbody_velocities_device(nbody_ctx *ctx);
+
+/* ---- the step: the bracket kernel.cu:1225-1242 = step(positions, velocities, masses, dt, softening) ----
+ * d_positions_xyzm : n_total float4, device, updated in place (rows of this context only).
+ * d_velocities_xyzw: row_count float4, device: velocities of rows row_lo.. (the whole array for nbody_create).
+ * d_masses         : NULL => mass is positions[4i+3] (the reference's only mode); else n_total floats that are
+ *                    first copied into positions[4i+3].
+ * dt               : TIME_TICK (kernel.cu:63; the reference uses 0.008).
+ * softening        : eps, a length; eps^2 replaces EPSILON (kernel.cu:66).  The reference's VERSION 3
+ *                    corresponds to 1e-2 and VERSIONs 1/2 to 1e-3.  0 is allowed: pairs
+ *                    at zero distance (the self pair included) then contribute nothing.
+ * nbody_step returns after the device work is complete (the reference synchronises at kernel.cu:1232,1236);
+ * nbody_step_async only enqueues on the context's stream; nbody_sync waits and reports kernel errors. */
+int nbody_step(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, const float *d_masses, float dt,
+               float softening);
+int nbody_step_async(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, const float *d_masses,
+                     float dt, float softening);
+int nbody_step_n(nbody_ctx *ctx, int k, float dt, float softening); /* k steps on the owned buffers, one sync */
+int nbody_sync(nbody_ctx *ctx);
+
+/* ---- the two halves of a step, for callers that interleave an exchange (multi-GPU) ----
+ * nbody_forces: partial accelerations of this context's rows from columns [col_lo, col_lo+col_count)
+ *   (cal_acc_advanced's job, kernel.cu:703-774, for a column range); col_lo must be a multiple of split_len
+ *   and the range must end on a split boundary or at n_total.  Asynchronous.
+ * nbody_update: adds the partials of ALL splits in ascending order and applies the kick-drift of
+ *   use_acc_update_position (kernel.cu:777-801) to this context's rows.  Asynchronous.
+ * Every split must have been produced by nbody_forces since the previous nbody_update. */
+int nbody_forces(nbody_ctx *ctx, const float *d_positions_xyzm, int64_t col_lo, int64_t col_count, float softening);
+int nbody_update(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, float dt);
+
+/* Run on the caller's HIP stream (a hipStream_t passed as void*); NULL restores the context's own stream. */
+int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);
+
+/* ---- diagnostics (the reference has none) ----
+ * nbody_energy: out = {kinetic, potential, total} of this context's rows against all columns
+ *   (potential = -1/2 sum_i m_i sum_{j!=i} m_j / sqrt(r^2+eps^2), fp32 pair terms, fp64 sums); for a
+ *   sharded run the caller adds the ranks' triples.  Synchronous.
+ * nbody_momentum: out = {px, py, pz, mass} of this context's rows.  Synchronous. */
+int nbody_energy(nbody_ctx *ctx, const float *d_positions_xyzm, const float *d_velocities_xyzw, float softening,
+                 double *out3);
+int nbody_momentum(nbody_ctx *ctx, const float *d_positions_xyzm, const float *d_velocities_xyzw, double *out4);
+
+/* ---- measurement: HIP-event timing of the kernels on the stream they run on ----
+ * With timing on, every force / update launch is bracketed by events.  nbody_timing_read synchronises,
+ * returns the accumulated milliseconds and launch counts since the last read, and resets them. */
+int nbody_timing_enable(nbody_ctx *ctx, int on);
+int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches, double *update_ms,
+                      int64_t *update_launches);
+
+/* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default). */
+int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
+
+/* Device facts for the roofline: out = {compute units, max clock MHz, wavefront size, LDS bytes per CU}. */
+int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_AMD_H */

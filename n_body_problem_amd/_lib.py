@@ -1,0 +1,90 @@
+"""ctypes binding of ``libnbody_amd.so`` -- one prototype per entry point of ``include/nbody.h``.
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+from .build import LIB_PATH
+
+NBODY_OK = 0
+NBODY_ERR_INVALID = -1
+NBODY_ERR_ALLOC = -2
+NBODY_ERR_DEVICE = -3
+NBODY_ERR_NO_DEVICE = -4
+NBODY_ERR_STATE = -5
+
+
+class NBodyError(RuntimeError):
+    """A C-ABI call returned a negative ``nbody_status``."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"nbody status {status}: {message}")
+        self.status = status
+
+
+_PROTOTYPES = {
+    # name: (restype, argtypes)
+    "nbody_abi_version": (c_int, []),
+    "nbody_status_string": (c_char_p, [c_int]),
+    "nbody_create": (c_int, [POINTER(c_void_p), c_int, c_int64]),
+    "nbody_create_shard": (c_int, [POINTER(c_void_p), c_int, c_int64, c_int64, c_int64, c_int64]),
+    "nbody_destroy": (c_int, [c_void_p]),
+    "nbody_last_error": (c_char_p, [c_void_p]),
+    "nbody_default_split_len": (c_int64, [c_int64]),
+    "nbody_split_len": (c_int64, [c_void_p]),
+    "nbody_n_total": (c_int64, [c_void_p]),
+    "nbody_set_positions": (c_int, [c_void_p, c_void_p]),
+    "nbody_set_velocities": (c_int, [c_void_p, c_void_p]),
+    "nbody_download": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nbody_positions_device": (c_void_p, [c_void_p]),
+    "nbody_velocities_device": (c_void_p, [c_void_p]),
+    "nbody_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float]),
+    "nbody_step_async": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float]),
+    "nbody_step_n": (c_int, [c_void_p, c_int, c_float, c_float]),
+    "nbody_sync": (c_int, [c_void_p]),
+    "nbody_forces": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
+    "nbody_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float]),
+    "nbody_set_stream": (c_int, [c_void_p, c_void_p]),
+    "nbody_energy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, POINTER(c_double)]),
+    "nbody_momentum": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
+    "nbody_timing_enable": (c_int, [c_void_p, c_int]),
+    "nbody_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
+                                  POINTER(c_int64)]),
+    "nbody_set_rows_per_lane": (c_int, [c_void_p, c_int]),
+    "nbody_device_info": (c_int, [c_void_p, POINTER(c_int64), c_char_p, c_int]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the in-tree shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950).  n_body_problem_amd has no CPU or PyTorch fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def exported_names():
+    return list(_PROTOTYPES)
+
+
+def check(status: int, ctx=None) -> None:
+    if status != NBODY_OK:
+        lib = load()
+        msg = lib.nbody_last_error(ctx) or b""
+        text = msg.decode("utf-8", "replace") or lib.nbody_status_string(status).decode()
+        raise NBodyError(status, text)

@@ -1,0 +1,53 @@
+"""Build recipe of ``libnbody_amd.so`` (HIP kernels + C ABI) for gfx950, in-tree.
+
+``hipcc`` cross-compiles without a GPU, so this runs in the build container as well as on the
+MI355X box.  The library links only ``libamdhip64``: no torch types cross the ABI
+(``include/nbody.h``).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libnbody_amd.so")
+SOURCES = ["nbody_kernels.hip", "nbody_capi.hip"]
+HEADERS = [os.path.join(CSRC, "nbody_kernels.h"), os.path.join(PKG_DIR, "..", "include", "nbody.h")]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built (no CPU fallback exists)")
+    return exe
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the shared library if missing or older than its sources; returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout + res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building libnbody_amd.so:\n" + res.stderr[-4000:])
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

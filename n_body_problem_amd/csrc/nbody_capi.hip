@@ -1,0 +1,506 @@
+// nbody_capi.hip -- the C ABI of include/nbody.h: context, buffers, step sequencing, timing.
+// Host side of the reference's buffer/interop boundary (main_project/kernel.cu:130-188, 1148-1160)
+// and of its per-frame step bracket (kernel.cu:1225-1242), for a headless MI355X.
+#include "../../include/nbody.h"
+#include "nbody_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace nbody;
+
+struct nbody_ctx {
+    int device = 0;
+    int64_t n_total = 0, row_lo = 0, row_count = 0, split_len = 0;
+    int n_splits = 0;
+    int rows_per_lane = 0;  // 0 = pick per launch
+    int cu_count = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream or the caller's)
+    float4 *partials = nullptr;    // [n_splits][row_count]  (the reference's gravity_sum_array, kernel.cu:1148)
+    float4 *pos = nullptr;         // owned position buffer (n_total), optional
+    float4 *vel = nullptr;         // owned velocity buffer (row_count), optional
+    double *reduce_dev = nullptr;  // per-block partials of the diagnostics kernels
+    std::vector<double> reduce_host;
+    std::vector<unsigned char> split_done;  // which splits nbody_forces has produced since the last update
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_force, ev_update;
+    std::vector<hipEvent_t> ev_pool;
+    double force_ms = 0, update_ms = 0;
+    int64_t force_launches = 0, update_launches = 0;
+    std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(nbody_ctx *c, int status, const std::string &msg)
+{
+    if (c)
+        c->err = msg;
+    else
+        g_create_error = msg;
+    return status;
+}
+
+#define HIP_TRY(c, call)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail((c), e_ == hipErrorOutOfMemory ? NBODY_ERR_ALLOC : NBODY_ERR_DEVICE,               \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                \
+    } while (0)
+
+extern "C" {
+
+int nbody_abi_version(void) { return NBODY_ABI_VERSION; }
+
+const char *nbody_status_string(int s)
+{
+    switch (s) {
+    case NBODY_OK: return "ok";
+    case NBODY_ERR_INVALID: return "invalid argument";
+    case NBODY_ERR_ALLOC: return "allocation failed";
+    case NBODY_ERR_DEVICE: return "HIP error";
+    case NBODY_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case NBODY_ERR_STATE: return "context buffers not initialised";
+    default: return "unknown status";
+    }
+}
+
+const char *nbody_last_error(const nbody_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int64_t nbody_default_split_len(int64_t n_total)
+{
+    // 16 splits of the columns, rounded up to whole 256-body tiles.  A function of n_total ONLY:
+    // split boundaries define the summation order, so they must not depend on the sharding.
+    if (n_total <= 0)
+        return kTile;
+    int64_t len = (n_total + 15) / 16;
+    return (len + kTile - 1) / kTile * kTile;
+}
+
+int64_t nbody_split_len(const nbody_ctx *ctx) { return ctx ? ctx->split_len : 0; }
+int64_t nbody_n_total(const nbody_ctx *ctx) { return ctx ? ctx->n_total : 0; }
+
+int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row_lo, int64_t row_count,
+                       int64_t split_len)
+{
+    if (!out)
+        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: out is NULL");
+    *out = nullptr;
+    if (n_total < 0 || n_total > (int64_t)1 << 30)
+        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: n_total out of range [0, 2^30]");
+    if (row_lo < 0 || row_count < 0 || row_lo + row_count > n_total)
+        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: rows [row_lo,row_lo+row_count) not inside [0,n_total)");
+    if (split_len == 0)
+        split_len = nbody_default_split_len(n_total);
+    if (split_len < 0 || split_len % kTile != 0)
+        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: split_len must be a positive multiple of 256");
+    if (row_lo % split_len != 0)
+        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: row_lo must be a multiple of split_len");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NBODY_ERR_NO_DEVICE,
+                    std::string("nbody_create: no HIP device (") + hipGetErrorString(e) +
+                        "); this library has no CPU path");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: device index out of range");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, NBODY_ERR_NO_DEVICE,
+                    std::string("nbody_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+
+    nbody_ctx *c = new (std::nothrow) nbody_ctx;
+    if (!c)
+        return fail(nullptr, NBODY_ERR_ALLOC, "nbody_create: host allocation failed");
+    c->device = device;
+    c->n_total = n_total;
+    c->row_lo = row_lo;
+    c->row_count = row_count;
+    c->split_len = split_len;
+    c->n_splits = (int)((n_total + split_len - 1) / split_len);
+    c->cu_count = prop.multiProcessorCount;
+    c->split_done.assign((size_t)c->n_splits, 0);
+
+    int rc = NBODY_OK;
+    auto guard = [&](hipError_t he, const char *what) {
+        if (he != hipSuccess && rc == NBODY_OK)
+            rc = fail(nullptr, he == hipErrorOutOfMemory ? NBODY_ERR_ALLOC : NBODY_ERR_DEVICE,
+                      std::string(what) + ": " + hipGetErrorString(he));
+    };
+    guard(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+    c->stream = c->own_stream;
+    size_t part_bytes = sizeof(float4) * (size_t)c->n_splits * (size_t)row_count;
+    if (rc == NBODY_OK && part_bytes)
+        guard(hipMalloc((void **)&c->partials, part_bytes), "hipMalloc(partials)");
+    size_t red = (size_t)std::max(1, energy_blocks((int)row_count)) * 4;
+    if (rc == NBODY_OK)
+        guard(hipMalloc((void **)&c->reduce_dev, red * sizeof(double)), "hipMalloc(reduce)");
+    c->reduce_host.resize(red);
+    if (rc != NBODY_OK) {
+        nbody_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return NBODY_OK;
+}
+
+int nbody_create(nbody_ctx **out, int device, int64_t n_total)
+{
+    return nbody_create_shard(out, device, n_total, 0, n_total, 0);
+}
+
+int nbody_destroy(nbody_ctx *c)
+{
+    if (!c)
+        return NBODY_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream)
+        (void)hipStreamSynchronize(c->own_stream);
+    for (auto &p : c->ev_force) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : c->ev_update) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->pos) (void)hipFree(c->pos);
+    if (c->vel) (void)hipFree(c->vel);
+    if (c->reduce_dev) (void)hipFree(c->reduce_dev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return NBODY_OK;
+}
+
+int nbody_set_stream(nbody_ctx *c, void *hip_stream)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return NBODY_OK;
+}
+
+int nbody_sync(nbody_ctx *c)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return NBODY_OK;
+}
+
+// ---- owned buffers --------------------------------------------------------------------------
+
+int nbody_set_positions(nbody_ctx *c, const float *host)
+{
+    if (!c || !host)
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_positions: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->pos && c->n_total)
+        HIP_TRY(c, hipMalloc((void **)&c->pos, sizeof(float4) * (size_t)c->n_total));
+    if (c->n_total) {
+        HIP_TRY(c, hipMemcpyAsync(c->pos, host, sizeof(float4) * (size_t)c->n_total, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return NBODY_OK;
+}
+
+int nbody_set_velocities(nbody_ctx *c, const float *host)
+{
+    if (!c || !host)
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_velocities: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->vel && c->row_count)
+        HIP_TRY(c, hipMalloc((void **)&c->vel, sizeof(float4) * (size_t)c->row_count));
+    if (c->row_count) {
+        HIP_TRY(c, hipMemcpyAsync(c->vel, host, sizeof(float4) * (size_t)c->row_count, hipMemcpyHostToDevice,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return NBODY_OK;
+}
+
+int nbody_download(nbody_ctx *c, float *host_pos, float *host_vel)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    if ((host_pos && !c->pos && c->n_total) || (host_vel && !c->vel && c->row_count))
+        return fail(c, NBODY_ERR_STATE, "nbody_download: buffers were never set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (host_pos && c->n_total)
+        HIP_TRY(c, hipMemcpyAsync(host_pos, c->pos, sizeof(float4) * (size_t)c->n_total, hipMemcpyDeviceToHost,
+                                  c->stream));
+    if (host_vel && c->row_count)
+        HIP_TRY(c, hipMemcpyAsync(host_vel, c->vel, sizeof(float4) * (size_t)c->row_count, hipMemcpyDeviceToHost,
+                                  c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NBODY_OK;
+}
+
+float *nbody_positions_device(nbody_ctx *c) { return c ? reinterpret_cast<float *>(c->pos) : nullptr; }
+float *nbody_velocities_device(nbody_ctx *c) { return c ? reinterpret_cast<float *>(c->vel) : nullptr; }
+
+// ---- timing ---------------------------------------------------------------------------------
+
+static hipError_t get_event(nbody_ctx *c, hipEvent_t *e)
+{
+    if (!c->ev_pool.empty()) {
+        *e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return hipSuccess;
+    }
+    return hipEventCreate(e);
+}
+
+struct TimedLaunch {
+    nbody_ctx *c;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
+    hipEvent_t a = nullptr, b = nullptr;
+    TimedLaunch(nbody_ctx *ctx, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : c(ctx), list(l)
+    {
+        if (c->timing && get_event(c, &a) == hipSuccess && get_event(c, &b) == hipSuccess)
+            (void)hipEventRecord(a, c->stream);
+        else
+            a = b = nullptr;
+    }
+    ~TimedLaunch()
+    {
+        if (a && b) {
+            (void)hipEventRecord(b, c->stream);
+            list->emplace_back(a, b);
+        }
+    }
+};
+
+int nbody_timing_enable(nbody_ctx *c, int on)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    c->timing = on != 0;
+    return NBODY_OK;
+}
+
+static int drain(nbody_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &l, double &ms, int64_t &n)
+{
+    for (auto &p : l) {
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, p.first, p.second));
+        ms += t;
+        ++n;
+        c->ev_pool.push_back(p.first);
+        c->ev_pool.push_back(p.second);
+    }
+    l.clear();
+    return NBODY_OK;
+}
+
+int nbody_timing_read(nbody_ctx *c, double *force_ms, int64_t *force_launches, double *update_ms,
+                      int64_t *update_launches)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = drain(c, c->ev_force, c->force_ms, c->force_launches);
+    if (rc == NBODY_OK)
+        rc = drain(c, c->ev_update, c->update_ms, c->update_launches);
+    if (rc != NBODY_OK)
+        return rc;
+    if (force_ms) *force_ms = c->force_ms;
+    if (force_launches) *force_launches = c->force_launches;
+    if (update_ms) *update_ms = c->update_ms;
+    if (update_launches) *update_launches = c->update_launches;
+    c->force_ms = c->update_ms = 0;
+    c->force_launches = c->update_launches = 0;
+    return NBODY_OK;
+}
+
+// ---- the step -------------------------------------------------------------------------------
+
+int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
+{
+    if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == 8))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_rows_per_lane: expected 0, 1, 2, 4 or 8");
+    c->rows_per_lane = rpl;
+    return NBODY_OK;
+}
+
+// Largest register blocking that still leaves every CU several workgroups.  Speed only: each
+// row's sum is the same FMA chain whatever the blocking.
+static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
+{
+    if (c->rows_per_lane)
+        return c->rows_per_lane;
+    const int64_t want = 4LL * c->cu_count;
+    for (int rpl : {4, 2}) {
+        int64_t blocks = (c->row_count + (int64_t)kTile * rpl - 1) / ((int64_t)kTile * rpl) * split_count;
+        if (blocks >= want)
+            return rpl;
+    }
+    return 1;
+}
+
+int nbody_forces(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t col_count, float softening)
+{
+    if (!c || (!d_pos && c->n_total))
+        return fail(c, NBODY_ERR_INVALID, "nbody_forces: NULL argument");
+    if (!(softening >= 0.f) || !std::isfinite(softening))
+        return fail(c, NBODY_ERR_INVALID, "nbody_forces: softening must be finite and >= 0");
+    if (col_lo < 0 || col_count < 0 || col_lo + col_count > c->n_total || col_lo % c->split_len != 0 ||
+        ((col_lo + col_count) % c->split_len != 0 && col_lo + col_count != c->n_total))
+        return fail(c, NBODY_ERR_INVALID, "nbody_forces: column range must be split-aligned and inside [0,n_total]");
+    if (col_count == 0 || c->row_count == 0)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ForceArgs a;
+    a.pos = reinterpret_cast<const float4 *>(d_pos);
+    a.partials = c->partials;
+    a.row_lo = (int)c->row_lo;
+    a.row_count = (int)c->row_count;
+    a.n_total = (int)c->n_total;
+    a.split_len = (int)c->split_len;
+    a.split_first = (int)(col_lo / c->split_len);
+    a.split_count = (int)((col_count + c->split_len - 1) / c->split_len);
+    a.eps2 = softening * softening;
+    {
+        TimedLaunch t(c, &c->ev_force);
+        HIP_TRY(c, launch_forces(a, pick_rows_per_lane(c, a.split_count), c->stream));
+    }
+    for (int s = 0; s < a.split_count; ++s)
+        c->split_done[(size_t)(a.split_first + s)] = 1;
+    return NBODY_OK;
+}
+
+int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
+{
+    if (!c || ((!d_pos || !d_vel) && c->row_count))
+        return fail(c, NBODY_ERR_INVALID, "nbody_update: NULL argument");
+    if (!std::isfinite(dt))
+        return fail(c, NBODY_ERR_INVALID, "nbody_update: dt must be finite");
+    if (c->row_count == 0)
+        return NBODY_OK;
+    for (int s = 0; s < c->n_splits; ++s)
+        if (!c->split_done[(size_t)s])
+            return fail(c, NBODY_ERR_STATE, "nbody_update: split " + std::to_string(s) +
+                                                " has no partial sums (call nbody_forces for every column range first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        TimedLaunch t(c, &c->ev_update);
+        HIP_TRY(c, launch_update(reinterpret_cast<float4 *>(d_pos), reinterpret_cast<float4 *>(d_vel), c->partials,
+                                 (int)c->row_lo, (int)c->row_count, c->n_splits, dt, c->stream));
+    }
+    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    return NBODY_OK;
+}
+
+int nbody_step_async(nbody_ctx *c, float *d_pos, float *d_vel, const float *d_masses, float dt, float softening)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    if ((!d_pos && c->n_total) || (!d_vel && c->row_count))
+        return fail(c, NBODY_ERR_INVALID, "nbody_step: NULL positions or velocities");
+    if (d_masses) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, launch_scatter_mass(reinterpret_cast<float4 *>(d_pos), d_masses, (int)c->n_total, c->stream));
+    }
+    int rc = nbody_forces(c, d_pos, 0, c->n_total, softening);
+    if (rc != NBODY_OK)
+        return rc;
+    if (c->n_total == 0)
+        return NBODY_OK;
+    return nbody_update(c, d_pos, d_vel, dt);
+}
+
+int nbody_step(nbody_ctx *c, float *d_pos, float *d_vel, const float *d_masses, float dt, float softening)
+{
+    int rc = nbody_step_async(c, d_pos, d_vel, d_masses, dt, softening);
+    return rc == NBODY_OK ? nbody_sync(c) : rc;
+}
+
+int nbody_step_n(nbody_ctx *c, int k, float dt, float softening)
+{
+    if (!c || k < 0)
+        return fail(c, NBODY_ERR_INVALID, "nbody_step_n: bad argument");
+    if ((c->n_total && !c->pos) || (c->row_count && !c->vel))
+        return fail(c, NBODY_ERR_STATE, "nbody_step_n: call nbody_set_positions and nbody_set_velocities first");
+    for (int s = 0; s < k; ++s) {
+        int rc = nbody_step_async(c, reinterpret_cast<float *>(c->pos), reinterpret_cast<float *>(c->vel), nullptr, dt,
+                                  softening);
+        if (rc != NBODY_OK)
+            return rc;
+    }
+    return nbody_sync(c);
+}
+
+// ---- diagnostics ----------------------------------------------------------------------------
+
+static int reduce_blocks(nbody_ctx *c, int nvals, double *out)
+{
+    const int blocks = energy_blocks((int)c->row_count);
+    HIP_TRY(c, hipMemcpyAsync(c->reduce_host.data(), c->reduce_dev, sizeof(double) * (size_t)blocks * nvals,
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int v = 0; v < nvals; ++v)
+        out[v] = 0.0;
+    for (int b = 0; b < blocks; ++b)
+        for (int v = 0; v < nvals; ++v)
+            out[v] += c->reduce_host[(size_t)b * nvals + v];
+    return NBODY_OK;
+}
+
+int nbody_energy(nbody_ctx *c, const float *d_pos, const float *d_vel, float softening, double *out3)
+{
+    if (!c || !out3 || ((!d_pos || !d_vel) && c->row_count))
+        return fail(c, NBODY_ERR_INVALID, "nbody_energy: NULL argument");
+    out3[0] = out3[1] = out3[2] = 0.0;
+    if (c->row_count == 0)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_energy(reinterpret_cast<const float4 *>(d_pos), reinterpret_cast<const float4 *>(d_vel),
+                             c->reduce_dev, (int)c->row_lo, (int)c->row_count, (int)c->n_total,
+                             softening * softening, c->stream));
+    double ku[2];
+    int rc = reduce_blocks(c, 2, ku);
+    if (rc != NBODY_OK)
+        return rc;
+    out3[0] = ku[0];
+    out3[1] = ku[1];
+    out3[2] = ku[0] + ku[1];
+    return NBODY_OK;
+}
+
+int nbody_momentum(nbody_ctx *c, const float *d_pos, const float *d_vel, double *out4)
+{
+    if (!c || !out4 || ((!d_pos || !d_vel) && c->row_count))
+        return fail(c, NBODY_ERR_INVALID, "nbody_momentum: NULL argument");
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+    if (c->row_count == 0)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_momentum(reinterpret_cast<const float4 *>(d_pos), reinterpret_cast<const float4 *>(d_vel),
+                               c->reduce_dev, (int)c->row_lo, (int)c->row_count, c->stream));
+    return reduce_blocks(c, 4, out4);
+}
+
+int nbody_device_info(nbody_ctx *c, int64_t *out4, char *name, int name_len)
+{
+    if (!c || !out4)
+        return NBODY_ERR_INVALID;
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    out4[0] = prop.multiProcessorCount;
+    out4[1] = prop.clockRate / 1000;  // kHz -> MHz
+    out4[2] = prop.warpSize;
+    out4[3] = (int64_t)prop.maxSharedMemoryPerMultiProcessor;
+    if (name && name_len > 0) {
+        std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    return NBODY_OK;
+}
+
+}  // extern "C"

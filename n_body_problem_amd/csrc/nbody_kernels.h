@@ -1,0 +1,43 @@
+// nbody_kernels.h -- launch interface between the C ABI (nbody_capi.hip) and the gfx950 kernels
+// (nbody_kernels.hip).  Internal; the public surface is include/nbody.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbody {
+
+constexpr int kTile = 256;  // bodies per LDS tile == threads per workgroup (reference BLOCK_SIZE, kernel.cu:65)
+
+struct ForceArgs {
+    const float4 *pos;   // all n_total bodies {x,y,z,m}
+    float4 *partials;    // [n_splits][row_count] partial accelerations {ax,ay,az,unused}
+    int row_lo;          // first row (global body index) of this context
+    int row_count;       // rows of this context
+    int n_total;         // columns
+    int split_len;       // columns per split (multiple of kTile)
+    int split_first;     // first split computed by this launch
+    int split_count;     // splits computed by this launch (grid.y)
+    float eps2;          // softening length squared
+};
+
+// Partial accelerations of rows [row_lo,row_lo+row_count) from splits [split_first, split_first+split_count).
+// rows_per_lane in {1,2,4,8}.  eps2 == 0 selects the zero-distance-guarded variant.
+hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stream);
+
+// Sum the partials of n_splits splits in ascending order and kick-drift rows of this context.
+hipError_t launch_update(float4 *pos_all, float4 *vel_rows, const float4 *partials, int row_lo, int row_count,
+                         int n_splits, float dt, hipStream_t stream);
+
+// positions[4i+3] = masses[i]
+hipError_t launch_scatter_mass(float4 *pos_all, const float *masses, int n_total, hipStream_t stream);
+
+// Per-block {kinetic, potential} doubles into block_out[2*gridDim.x]; returns the grid size used.
+hipError_t launch_energy(const float4 *pos_all, const float4 *vel_rows, double *block_out, int row_lo,
+                         int row_count, int n_total, float eps2, hipStream_t stream);
+int energy_blocks(int row_count);
+
+// Per-block {px,py,pz,m} doubles into block_out[4*gridDim.x].
+hipError_t launch_momentum(const float4 *pos_all, const float4 *vel_rows, double *block_out, int row_lo,
+                           int row_count, hipStream_t stream);
+
+}  // namespace nbody

@@ -1,0 +1,231 @@
+"""Rows sharded over the GPUs of one node: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
+
+The reference is single-GPU (nothing to mirror); the path shards naturally because the
+rows of the interaction matrix are independent given all positions:
+
+* rank r integrates the contiguous rows ``[r*C, (r+1)*C)`` (its velocities, its partial sums) and holds a
+  full-size replica of the position buffer (16 MiB at N = 2^20);
+* per step ONE exchange, the all-gather of the updated position slices (C x 16 B per rank), overlapped
+  with the force kernel on the rank's OWN column chunk, which needs no remote data; only then does the
+  compute stream wait for remote chunks.
+
+``exchange="allgather"``: one in-place RCCL all-gather per step (RCCL runs it as a ring over xGMI), issued
+right after the update kernel; the next step's own-chunk force kernel runs beside it.
+``exchange="ring"``: the ring spelled out as P-1 send/recv hops on a communication stream; the force
+kernel of chunk (r-h) starts as soon as hop h has landed, while later hops are still on the wire.
+
+Determinism: chunk boundaries are multiples of ``split_len`` (a function of the body count only), every
+split's partial sum is one ascending FMA chain and the splits are added in ascending order, so the state
+is bit-identical to the single-GPU run for any world size, exchange mode and chunk arrival order.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import system as _system
+
+
+def shard_geometry(num_bodies: int, world_size: int, split_len: int):
+    """(padded body count, rows per rank).  Rows per rank are a whole number of splits."""
+    n_splits = max(1, -(-num_bodies // split_len))
+    splits_per_rank = -(-n_splits // world_size)
+    chunk = splits_per_rank * split_len
+    return chunk * world_size, chunk
+
+
+def ring_schedule(rank: int, world_size: int):
+    """[(hop, chunk sent to rank+1, chunk received from rank-1)] for hops 1..P-1 of a ring all-gather."""
+    return [(h, (rank - h + 1) % world_size, (rank - h) % world_size) for h in range(1, world_size)]
+
+
+class ShardedNBodySystem:
+    """The reference's step interface (see :mod:`n_body_problem_amd.system`) for one rank of a sharded run.
+
+    ``kernels_factory(n_padded, row_lo, row_count, split_len)`` must return an object with the interface of
+    :class:`NBodySystem` (``positions``, ``velocities``, ``forces``, ``update``, ``sync``, ``energy``,
+    ``momentum``).  The default -- and the only one the package ships -- is the HIP-backed ``NBodySystem``;
+    tests inject a CPU stand-in to exercise the sharding and exchange logic under ``gloo``.
+    """
+
+    def __init__(self, num_bodies: int, group=None, device: Optional[int] = None, exchange: str = "allgather",
+                 kernels_factory: Optional[Callable] = None, split_len: int = 0):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        if exchange not in ("allgather", "ring"):
+            raise ValueError("exchange must be 'allgather' or 'ring'")
+        self.exchange = exchange
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.world_size = dist.get_world_size(group) if self.distributed else 1
+        self.num_bodies = int(num_bodies)
+        if kernels_factory is None:
+            self.split_len = int(split_len) or _system.default_split_len(self.num_bodies)
+        else:
+            if not split_len:
+                raise ValueError("a custom kernels_factory needs an explicit split_len")
+            self.split_len = int(split_len)
+        self.n_padded, self.chunk = shard_geometry(self.num_bodies, self.world_size, self.split_len)
+        self.row_lo = self.rank * self.chunk
+        if kernels_factory is None:
+            dev = torch.cuda.current_device() if device is None else device
+            self.kernels = _system.NBodySystem(self.n_padded, device=dev, row_lo=self.row_lo, row_count=self.chunk,
+                                               split_len=self.split_len)
+        else:
+            self.kernels = kernels_factory(self.n_padded, self.row_lo, self.chunk, self.split_len)
+        self.positions = self.kernels.positions      # full replica, (n_padded, 4)
+        self.velocities = self.kernels.velocities    # own rows, (chunk, 4)
+        self._on_gpu = bool(self.positions.is_cuda)
+        self._send = None if self._on_gpu else torch.empty_like(self.positions[:self.chunk])
+        self._comm_stream = torch.cuda.Stream(device=self.positions.device) if self._on_gpu else None
+        self._pending = None   # allgather mode: work handle of the exchange in flight
+        self._stale = False    # ring mode: remote chunks of the replica are one update behind
+
+    # -- buffers ----------------------------------------------------------------------------------
+    def _pad(self, data) -> np.ndarray:
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
+        if a.shape[0] != self.num_bodies:
+            raise ValueError(f"expected {self.num_bodies} bodies, got {a.shape[0]}")
+        out = np.zeros((self.n_padded, 4), dtype=np.float32)  # zero-mass bodies at the origin, as kernel.cu:265-277
+        out[:self.num_bodies] = a
+        return out
+
+    def setParticlesPosition(self, data) -> None:
+        self._refresh()
+        self.positions.copy_(self._torch.from_numpy(self._pad(data)))
+
+    def setParticlesVelocity(self, data) -> None:
+        v = self._pad(data)[self.row_lo:self.row_lo + self.chunk]
+        self.velocities.copy_(self._torch.from_numpy(np.ascontiguousarray(v)))
+
+    set_particles_position = setParticlesPosition
+    set_particles_velocity = setParticlesVelocity
+
+    def download(self):
+        """Full (positions, velocities) of the real bodies on every rank (velocities are gathered)."""
+        torch, dist = self._torch, self._dist
+        self.sync()
+        vel = self.velocities
+        if self.world_size > 1:
+            parts = [torch.empty_like(vel) for _ in range(self.world_size)]
+            dist.all_gather(parts, vel.contiguous(), group=self.group)
+            vel = torch.cat(parts)
+        n = self.num_bodies
+        return self.positions[:n].cpu().numpy(), vel[:n].cpu().numpy()
+
+    # -- exchange -----------------------------------------------------------------------------------
+    def _chunk(self, c: int):
+        return self.positions[c * self.chunk:(c + 1) * self.chunk]
+
+    def _drain(self) -> None:
+        """allgather mode: make the current stream (for gloo: the host) wait for the exchange in flight."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    def _start_allgather(self) -> None:
+        dist = self._dist
+        if self._on_gpu:
+            # in place: RCCL recognises sendbuff == recvbuff + rank*count and skips the self copy, so the
+            # own chunk is never written while the next step's own-chunk force kernel reads it
+            send = self._chunk(self.rank)
+        else:
+            self._send.copy_(self._chunk(self.rank))
+            send = self._send
+        self._pending = dist.all_gather_into_tensor(self.positions, send, group=self.group, async_op=True)
+
+    def _peer(self, r: int) -> int:
+        r %= self.world_size
+        return self._dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _ring_hop(self, send_c: int, recv_c: int) -> None:
+        """One hop: chunk send_c goes to rank+1 while chunk recv_c arrives from rank-1, in place in the replica.
+        On return the CURRENT stream is ordered after the arrival; the hop itself runs on the comm stream."""
+        torch, dist = self._torch, self._dist
+        ops = [dist.P2POp(dist.isend, self._chunk(send_c), self._peer(self.rank + 1), group=self.group),
+               dist.P2POp(dist.irecv, self._chunk(recv_c), self._peer(self.rank - 1), group=self.group)]
+        if self._on_gpu:
+            with torch.cuda.stream(self._comm_stream):
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()  # orders the comm stream (not the host) after the transfer
+                landed = torch.cuda.Event()
+                landed.record(self._comm_stream)
+            torch.cuda.current_stream(self.positions.device).wait_event(landed)
+        else:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def _refresh(self) -> None:
+        """Bring every chunk of the replica up to date without computing anything."""
+        self._drain()
+        if self._stale:
+            if self._on_gpu:
+                self._comm_stream.wait_stream(self._torch.cuda.current_stream(self.positions.device))
+            for _, send_c, recv_c in ring_schedule(self.rank, self.world_size):
+                self._ring_hop(send_c, recv_c)
+            self._stale = False
+
+    # -- the step -------------------------------------------------------------------------------------
+    def step(self, dt: float = _system.TIME_TICK, softening: float = _system.SOFTENING_VERSION3,
+             sync: bool = True) -> None:
+        k = self.kernels
+        lo, hi = self.row_lo, self.row_lo + self.chunk
+        if self._stale:  # ring mode, remote chunks outstanding
+            if self._on_gpu:  # hops may start once the previous update (already enqueued) has written the own rows
+                self._comm_stream.wait_stream(self._torch.cuda.current_stream(self.positions.device))
+            k.forces(lo, self.chunk, softening)              # own chunk: runs beside the first hops
+            for _, send_c, recv_c in ring_schedule(self.rank, self.world_size):
+                self._ring_hop(send_c, recv_c)
+                k.forces(recv_c * self.chunk, self.chunk, softening)
+            self._stale = False
+        else:
+            k.forces(lo, self.chunk, softening)              # own chunk: runs beside the all-gather in flight
+            self._drain()
+            if lo > 0:
+                k.forces(0, lo, softening)
+            if hi < self.n_padded:
+                k.forces(hi, self.n_padded - hi, softening)
+        k.update(dt)
+        if self.world_size > 1:
+            if self.exchange == "allgather":
+                self._start_allgather()
+            else:
+                self._stale = True
+        if sync:
+            self.sync()
+
+    def step_n(self, n: int, dt: float = _system.TIME_TICK, softening: float = _system.SOFTENING_VERSION3) -> None:
+        for _ in range(int(n)):
+            self.step(dt, softening, sync=False)
+        self.sync()
+
+    def sync(self) -> None:
+        """Replica current on every rank and all device work complete."""
+        self._refresh()
+        self.kernels.sync()
+
+    # -- diagnostics ------------------------------------------------------------------------------------
+    def _allreduce(self, vals: np.ndarray) -> np.ndarray:
+        if self.world_size == 1:
+            return vals
+        torch, dist = self._torch, self._dist
+        t = torch.from_numpy(vals.copy()).to(self.positions.device)
+        dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
+    def energy(self, softening: float) -> np.ndarray:
+        """[kinetic, potential, total] of the whole system (each rank's rows, summed over ranks)."""
+        self.sync()
+        return self._allreduce(np.asarray(self.kernels.energy(softening), dtype=np.float64))
+
+    def momentum(self) -> np.ndarray:
+        self.sync()
+        return self._allreduce(np.asarray(self.kernels.momentum(), dtype=np.float64))
+
+    def close(self) -> None:
+        self._refresh()
+        if hasattr(self.kernels, "close"):
+            self.kernels.close()

@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference's step interface, over the C ABI of ``libnbody_amd.so``.
+
+The reference has no library API; its "operator interface" for this path is (main_project/kernel.cu):
+
+* ``initialize(numBodies)``                       :130-161  allocate the position VBO + velocity buffer
+* ``setParticlesPosition(data)``                  :163-177  host float4 {x,y,z,mass} -> device
+* ``setParticlesVelocity(data)``                  :179-188  host float4 {vx,vy,vz,eps} -> device
+* the per-frame bracket                           :1225-1242 = ``step(positions, velocities, masses, dt, softening)``
+
+:class:`NBodySystem` keeps those names (plus snake_case aliases) and the same argument meaning.
+Device memory and streams come from PyTorch-ROCm (plumbing only); all arithmetic happens in the
+hand-written HIP kernels behind ``include/nbody.h``.  There is no CPU or PyTorch fallback: without
+the built library or without a gfx950 device every constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import NBodyError, check
+
+#: the reference's compile-time constants (kernel.cu:63, :66 and SURVEY.md 8a for the effective values)
+TIME_TICK = 0.008
+SOFTENING_VERSION3 = 1.0e-2  # cal_single_acclerate_without_mass_new: 0.1 pre-scale => eps^2 = 1e-4
+SOFTENING_VERSION1 = 1.0e-3  # cal_single_acclerate: eps^2 = EPSILON = 1e-6
+BLOCK_SIZE = 256
+
+
+def _torch():
+    import torch  # imported lazily: the ctypes layer itself does not need torch
+    return torch
+
+
+def _ptr(t) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
+
+
+def default_split_len(n_total: int) -> int:
+    """Columns per partial sum for ``n_total`` bodies (a function of ``n_total`` only)."""
+    return int(_lib.load().nbody_default_split_len(int(n_total)))
+
+
+class NBodySystem:
+    """One context = one GPU's rows ``[row_lo, row_lo+row_count)`` against all ``num_bodies`` columns.
+
+    With the defaults it is the reference's single-GPU system: ``initialize(numBodies)``.
+    """
+
+    def __init__(self, num_bodies: int, device: int = 0, row_lo: int = 0, row_count: Optional[int] = None,
+                 split_len: int = 0):
+        self._ctx = ctypes.c_void_p(None)
+        self._lib = _lib.load()
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise NBodyError(_lib.NBODY_ERR_NO_DEVICE, "no HIP device visible to PyTorch; there is no CPU path")
+        self.num_bodies = int(num_bodies)
+        self.row_lo = int(row_lo)
+        self.row_count = self.num_bodies - self.row_lo if row_count is None else int(row_count)
+        self.device = torch.device("cuda", device)
+        ctx = ctypes.c_void_p(None)
+        check(self._lib.nbody_create_shard(ctypes.byref(ctx), device, self.num_bodies, self.row_lo, self.row_count,
+                                           int(split_len)), None)
+        self._ctx = ctx
+        self.split_len = int(self._lib.nbody_split_len(ctx))
+        # the reference's two device buffers: position "VBO" (all bodies) and velocities (own rows)
+        self.positions = torch.zeros((self.num_bodies, 4), dtype=torch.float32, device=self.device)
+        self.velocities = torch.zeros((self.row_count, 4), dtype=torch.float32, device=self.device)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.nbody_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p(None)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _use_current_stream(self) -> None:
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._lib.nbody_set_stream(self._ctx, ctypes.c_void_p(s)), self._ctx)
+
+    # -- buffers (kernel.cu:163-188) ----------------------------------------------------------
+    def setParticlesPosition(self, data) -> None:
+        """Host ``float4 {x,y,z,mass}`` for ALL bodies -> the device position buffer."""
+        torch = _torch()
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
+        if a.shape[0] != self.num_bodies:
+            raise ValueError(f"expected {self.num_bodies} bodies, got {a.shape[0]}")
+        self.positions.copy_(torch.from_numpy(a))
+
+    def setParticlesVelocity(self, data) -> None:
+        """Host ``float4 {vx,vy,vz,eps}`` -> the device velocity buffer.
+
+        Accepts all ``num_bodies`` rows (this context's slice is taken) or exactly its own rows."""
+        torch = _torch()
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
+        if a.shape[0] == self.num_bodies:
+            a = a[self.row_lo:self.row_lo + self.row_count]
+        if a.shape[0] != self.row_count:
+            raise ValueError(f"expected {self.row_count} or {self.num_bodies} velocity rows, got {a.shape[0]}")
+        self.velocities.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+
+    set_particles_position = setParticlesPosition
+    set_particles_velocity = setParticlesVelocity
+
+    def download(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(positions, velocities) as host float32 arrays."""
+        return self.positions.cpu().numpy(), self.velocities.cpu().numpy()
+
+    # -- the step (kernel.cu:1225-1242) ---------------------------------------------------------
+    def step(self, dt: float = TIME_TICK, softening: float = SOFTENING_VERSION3, masses=None, sync: bool = True):
+        """One step in place on ``self.positions`` / ``self.velocities``.
+
+        ``masses`` (optional device tensor of ``num_bodies`` floats) is first copied into
+        ``positions[:,3]``; the default, as in the reference, is that mass already lives there."""
+        self._use_current_stream()
+        fn = self._lib.nbody_step if sync else self._lib.nbody_step_async
+        check(fn(self._ctx, _ptr(self.positions), _ptr(self.velocities), _ptr(masses), float(dt), float(softening)),
+              self._ctx)
+
+    def step_n(self, k: int, dt: float = TIME_TICK, softening: float = SOFTENING_VERSION3) -> None:
+        """``k`` steps enqueued back to back, one synchronisation at the end."""
+        self._use_current_stream()
+        for _ in range(int(k)):
+            check(self._lib.nbody_step_async(self._ctx, _ptr(self.positions), _ptr(self.velocities), None, float(dt),
+                                             float(softening)), self._ctx)
+        self.sync()
+
+    def forces(self, col_lo: int, col_count: int, softening: float, positions=None) -> None:
+        """Partial accelerations of this context's rows from columns ``[col_lo, col_lo+col_count)`` (async)."""
+        self._use_current_stream()
+        p = self.positions if positions is None else positions
+        check(self._lib.nbody_forces(self._ctx, _ptr(p), int(col_lo), int(col_count), float(softening)), self._ctx)
+
+    def update(self, dt: float, positions=None, velocities=None) -> None:
+        """Sum the partials of all splits and kick-drift this context's rows (async)."""
+        self._use_current_stream()
+        p = self.positions if positions is None else positions
+        v = self.velocities if velocities is None else velocities
+        check(self._lib.nbody_update(self._ctx, _ptr(p), _ptr(v), float(dt)), self._ctx)
+
+    def sync(self) -> None:
+        check(self._lib.nbody_sync(self._ctx), self._ctx)
+
+    # -- diagnostics -----------------------------------------------------------------------------
+    def energy(self, softening: float) -> np.ndarray:
+        """[kinetic, potential, total] of this context's rows (fp64)."""
+        self._use_current_stream()
+        out = (ctypes.c_double * 3)()
+        check(self._lib.nbody_energy(self._ctx, _ptr(self.positions), _ptr(self.velocities), float(softening), out),
+              self._ctx)
+        return np.array(list(out), dtype=np.float64)
+
+    def momentum(self) -> np.ndarray:
+        """[px, py, pz, mass] of this context's rows (fp64)."""
+        self._use_current_stream()
+        out = (ctypes.c_double * 4)()
+        check(self._lib.nbody_momentum(self._ctx, _ptr(self.positions), _ptr(self.velocities), out), self._ctx)
+        return np.array(list(out), dtype=np.float64)
+
+    # -- measurement -----------------------------------------------------------------------------
+    def timing(self, on: bool = True) -> None:
+        check(self._lib.nbody_timing_enable(self._ctx, 1 if on else 0), self._ctx)
+
+    def read_timing(self) -> dict:
+        """HIP-event totals since the last read: force/update milliseconds and launch counts."""
+        f_ms, u_ms = ctypes.c_double(0), ctypes.c_double(0)
+        f_n, u_n = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.nbody_timing_read(self._ctx, ctypes.byref(f_ms), ctypes.byref(f_n), ctypes.byref(u_ms),
+                                          ctypes.byref(u_n)), self._ctx)
+        return {"force_ms": f_ms.value, "force_launches": f_n.value, "update_ms": u_ms.value,
+                "update_launches": u_n.value}
+
+    def set_rows_per_lane(self, rpl: int) -> None:
+        check(self._lib.nbody_set_rows_per_lane(self._ctx, int(rpl)), self._ctx)
+
+    def device_info(self) -> dict:
+        out = (ctypes.c_int64 * 4)()
+        name = ctypes.create_string_buffer(128)
+        check(self._lib.nbody_device_info(self._ctx, out, name, 128), self._ctx)
+        return {"compute_units": out[0], "clock_mhz": out[1], "wavefront": out[2], "lds_per_cu": out[3],
+                "name": name.value.decode()}
+
+
+def initialize(num_bodies: int, device: int = 0) -> NBodySystem:
+    """``initialize(numBodies)`` of kernel.cu:130-161."""
+    return NBodySystem(num_bodies, device=device)
+
+
+_STEP_CACHE: dict = {}
+
+
+def step(positions, velocities, masses=None, dt: float = TIME_TICK, softening: float = SOFTENING_VERSION3):
+    """``step(positions, velocities, masses, dt, softening)`` on caller-owned device tensors, in place.
+
+    ``positions``: (n,4) float32 CUDA tensor {x,y,z,mass}; ``velocities``: (n,4) float32 CUDA tensor;
+    ``masses``: None (mass is ``positions[:,3]``, the reference's layout) or an (n,) float32 CUDA tensor.
+    Synchronous, like the reference's bracket (kernel.cu:1232,1236)."""
+    torch = _torch()
+    if not (positions.is_cuda and velocities.is_cuda):
+        raise NBodyError(_lib.NBODY_ERR_NO_DEVICE, "step() takes device tensors; there is no CPU path")
+    if positions.dtype != torch.float32 or velocities.dtype != torch.float32:
+        raise TypeError("positions and velocities must be float32")
+    if not (positions.is_contiguous() and velocities.is_contiguous()):
+        raise ValueError("positions and velocities must be contiguous (n,4) buffers")
+    n = positions.shape[0]
+    if positions.shape != (n, 4) or velocities.shape != (n, 4):
+        raise ValueError("expected (n,4) positions and velocities")
+    if masses is not None and (masses.dtype != torch.float32 or masses.numel() != n or not masses.is_cuda):
+        raise ValueError("masses must be an (n,) float32 device tensor")
+    key = (positions.device.index or 0, n)
+    lib = _lib.load()
+    ctx = _STEP_CACHE.get(key)
+    if ctx is None:
+        ctx = ctypes.c_void_p(None)
+        check(lib.nbody_create(ctypes.byref(ctx), key[0], n), None)
+        _STEP_CACHE[key] = ctx
+    s = torch.cuda.current_stream(positions.device).cuda_stream
+    check(lib.nbody_set_stream(ctx, ctypes.c_void_p(s)), ctx)
+    check(lib.nbody_step(ctx, _ptr(positions), _ptr(velocities), _ptr(masses), float(dt), float(softening)), ctx)

@@ -1,0 +1,157 @@
+"""CPU-only: pins the oracle (oracle/nbody_oracle.c) with analytic known answers and the committed
+fixtures.  The reference has no tests or golden vectors for this path, so these
+known answers are what stands between the restatement and a typo."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_state_error
+
+
+def two_bodies(d=1.0, m0=1.0, m1=1.0):
+    pos = np.array([[0, 0, 0, m0], [d, 0, 0, m1]], dtype=np.float32)
+    vel = np.zeros((2, 4), dtype=np.float32)
+    return pos, vel
+
+
+def test_unit_pair_known_answer(oracle_mod):
+    # unit masses at distance 1 -> |a| = (1+eps^2)^(-3/2), pointing at the other body
+    for eps in (0.0, 1e-3, 1e-2, 0.5):
+        pos, _ = two_bodies()
+        a = oracle_mod.accel_f32(pos, eps=eps, threads=1)
+        want = (1.0 + eps * eps) ** -1.5
+        assert a[0, 0] == pytest.approx(want, rel=3e-7) and a[1, 0] == pytest.approx(-want, rel=3e-7)
+        assert np.all(a[:, 1:] == 0)
+        a64 = oracle_mod.accel_f64(pos, eps=eps, threads=1)
+        assert a64[0, 0] == pytest.approx(want, rel=1e-14)
+
+
+def test_mass_weighting_and_newton_third_law(oracle_mod):
+    pos, _ = two_bodies(d=2.0, m0=3.0, m1=5.0)
+    a = oracle_mod.accel_f64(pos, eps=0.0, threads=1)
+    assert a[0, 0] == pytest.approx(5.0 / 4.0) and a[1, 0] == pytest.approx(-3.0 / 4.0)
+    # m0*a0 + m1*a1 = 0
+    assert 3.0 * a[0, 0] + 5.0 * a[1, 0] == pytest.approx(0.0, abs=1e-15)
+
+
+def test_coincident_and_self_pairs_contribute_zero(oracle_mod):
+    pos = np.array([[0.5, 0.5, 0.5, 1.0], [0.5, 0.5, 0.5, 2.0]], dtype=np.float32)
+    for eps in (0.0, 1e-3):
+        assert np.all(oracle_mod.accel_f32(pos, eps=eps, threads=1) == 0)
+        assert np.all(oracle_mod.accel_f64(pos, eps=eps, threads=1) == 0)
+
+
+def test_zero_mass_padding_changes_nothing(oracle_mod):
+    # the reference pads to roundup(n,256)+1 with zero-mass bodies at the origin (kernel.cu:260-278)
+    from n_body_problem_amd import initial_conditions as ic
+    pos, vel = ic.uniform_cube(100, seed=3)
+    ppos, pvel = ic.pad_reference_style(pos, vel)
+    assert ppos.shape[0] == 257 == ic.padded_count(100)
+    a = oracle_mod.accel_f32(pos, eps=1e-3, threads=1)
+    ap = oracle_mod.accel_f32(ppos, eps=1e-3, threads=1)
+    assert np.array_equal(a, ap[:100])
+    p1, v1 = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=3, threads=1)
+    p2, v2 = oracle_mod.step_f32(ppos, pvel, 1e-3, 1e-3, nsteps=3, threads=1)
+    assert np.array_equal(p1, p2[:100]) and np.array_equal(v1, v2[:100])
+
+
+def test_reference_pair_functions_match_general_form(oracle_mod):
+    # VERSION 3's pair function (0.1 pre-scale, EPSILON=1e-6) is the general form with eps = 1e-2;
+    # VERSION 1's (sqrtf + divide) is the general form with eps = 1e-3.
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        a = rng.uniform(-1, 1, 4).astype(np.float32)
+        b = rng.uniform(-1, 1, 4).astype(np.float32)
+        b[3] = abs(b[3]) + 0.1
+        pos = np.stack([a, b])
+        f3 = oracle_mod.pair_v3(a, b) * b[3]
+        g3 = oracle_mod.accel_f64(pos, 0, 1, eps=1e-2, threads=1)[0]
+        assert np.allclose(f3, g3, rtol=2e-6, atol=1e-9)
+        f1 = oracle_mod.pair_v1(a, b)
+        g1 = oracle_mod.accel_f64(pos, 0, 1, eps=1e-3, threads=1)[0]
+        assert np.allclose(f1, g1, rtol=2e-6, atol=1e-9)
+
+
+def test_version3_step_matches_general_step_with_reference_constants(oracle_mod):
+    # the parity target: reference VERSION 3 (pair-once, +/- application, dt=0.008) vs step(dt=0.008, eps=1e-2)
+    from n_body_problem_amd import initial_conditions as ic
+    pos, vel = ic.plummer(300, seed=9)
+    ppos, pvel = ic.pad_reference_style(pos, vel)
+    p3, v3 = oracle_mod.step_v3(ppos, pvel, nsteps=5)
+    pg, vg = oracle_mod.step_f32(pos, vel, 0.008, 1e-2, nsteps=5, threads=1)
+    assert rel_state_error(p3[:300], pg) < 2e-6
+    assert rel_state_error(v3[:300], vg) < 2e-6
+    # and VERSION 2 (Gauss-Seidel, in place) is NOT the same step
+    p2, _ = oracle_mod.step_v2_serial(pos, vel, nsteps=5)
+    pg1, _ = oracle_mod.step_f32(pos, vel, 0.008, 1e-3, nsteps=5, threads=1)
+    assert rel_state_error(p2, pg1) > 1e-7
+
+
+def test_update_is_kick_then_drift_with_new_velocity(oracle_mod):
+    pos = np.array([[1, 2, 3, 1]], dtype=np.float32)
+    vel = np.array([[0.5, 0, -1, 7]], dtype=np.float32)
+    acc = np.array([[2, 4, 8]], dtype=np.float32)
+    oracle_mod.update_f32(pos, vel, acc, 0.25)
+    assert np.allclose(vel[0], [1.0, 1.0, 1.0, 7.0])           # v + a*dt ; .w untouched
+    assert np.allclose(pos[0], [1.25, 2.25, 3.25, 1.0])        # x + v_new*dt ; mass untouched
+
+
+def test_f32_path_tracks_f64_truth(oracle_mod):
+    from n_body_problem_amd import initial_conditions as ic
+    pos, vel = ic.plummer(2048, seed=21)
+    a32 = oracle_mod.accel_f32(pos, eps=1e-3)
+    a64 = oracle_mod.accel_f64(pos, eps=1e-3)
+    err = np.linalg.norm(a32 - a64) / np.linalg.norm(a64)
+    assert err < 1e-6
+    p32, v32 = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=10)
+    p64, v64 = oracle_mod.step_f64(pos, vel, 1e-3, 1e-3, nsteps=10)
+    assert rel_state_error(p32, p64) < 1e-6 and rel_state_error(v32, v64) < 1e-5
+
+
+def test_threads_do_not_change_results(oracle_mod):
+    from n_body_problem_amd import initial_conditions as ic
+    pos, vel = ic.plummer(777, seed=2)
+    a1 = oracle_mod.accel_f32(pos, eps=1e-3, threads=1)
+    a8 = oracle_mod.accel_f32(pos, eps=1e-3, threads=8)
+    assert np.array_equal(a1, a8)
+    # column ranges add up to the whole (fp64, order-insensitive to 1e-13)
+    a = oracle_mod.accel_f64(pos, eps=1e-3)
+    b = oracle_mod.accel_f64(pos, j0=0, j1=300, eps=1e-3) + oracle_mod.accel_f64(pos, j0=300, j1=777, eps=1e-3)
+    assert np.allclose(a, b, rtol=1e-12, atol=1e-15)
+
+
+def test_momentum_and_energy_conservation(oracle_mod):
+    # BASELINE.json configs[0]: N=1024, softening=1e-3, dt=1e-3, 100 leapfrog steps, scalar CPU path
+    from n_body_problem_amd import initial_conditions as ic
+    pos, vel = ic.plummer(1024, seed=ic.CONFIG_SEED[1])
+    e0 = oracle_mod.energy(pos, vel, 1e-3)
+    m0 = oracle_mod.momentum(pos, vel)
+    p, v = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=100)
+    e1 = oracle_mod.energy(p, v, 1e-3)
+    m1 = oracle_mod.momentum(p, v)
+    assert abs(e1[2] - e0[2]) / abs(e0[2]) < 2e-4     # symplectic Euler: bounded drift
+    assert np.abs(m1[:3] - m0[:3]).max() < 1e-6        # sum m a = 0 up to fp32 rounding
+    assert e0[0] / abs(e0[1]) == pytest.approx(0.5, abs=0.05)   # virial equilibrium of the Plummer model
+
+
+def test_energy_known_answer(oracle_mod):
+    pos, vel = two_bodies(d=2.0, m0=3.0, m1=5.0)
+    vel[0, :3] = [1, 0, 0]
+    e = oracle_mod.energy(pos, vel, 0.0)
+    assert e[0] == pytest.approx(1.5) and e[1] == pytest.approx(-7.5) and e[2] == pytest.approx(-6.0)
+
+
+def test_golden_fixtures_reproduce(oracle_mod, golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "f1_*.npz")))
+    assert len(files) >= 4
+    for f in files:
+        g = np.load(f)
+        dt, eps = float(g["dt"]), float(g["softening"])
+        for k in g["steps"]:
+            if k > 10 and g["pos0"].shape[0] > 300:
+                continue  # keep the CPU suite short; K=100 at n=1024 is covered by the conservation test
+            p, v = oracle_mod.step_f32(g["pos0"], g["vel0"], dt, eps, nsteps=int(k), threads=1)
+            assert np.array_equal(p, g[f"p32_{k}"]) and np.array_equal(v, g[f"v32_{k}"]), (f, k)
+            assert rel_state_error(p, g[f"p64_{k}"]) < (1e-6 if k <= 10 else 1e-5)

@@ -1,0 +1,300 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Stated tolerances (fp32 arithmetic, v_rsq_f32 <= 1 ulp, summation order differs from
+the oracle's single ascending chain):
+  * one-step accelerations vs the fp64 truth: relative L2 error <= 1e-5 (measured ~1e-7);
+  * state after K steps vs the reference-order fp32 oracle: max|x - x_ref|_inf / max|x_ref|_inf <= 1e-5,
+    same for v (BASELINE.json configs[1]: N = 65 536, K = 10);
+  * GPU vs GPU (different register blocking, row shards, column ranges): BIT-EXACT.
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_state_error
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def nb():
+    import torch
+    import n_body_problem_amd as nb
+    assert torch.cuda.is_available(), "the gpu suite needs an MI355X"
+    return nb
+
+
+def run_gpu(nb, pos, vel, dt, eps, nsteps, **kw):
+    with nb.NBodySystem(pos.shape[0], **kw) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(nsteps, dt, eps)
+        return s.download()
+
+
+def gpu_accel(nb, pos, eps, rpl=0):
+    """Accelerations recovered from one step with dt=1 and v=0: v_new = a exactly (fp64 FMA, then rounded)."""
+    vel = np.zeros_like(pos)
+    with nb.NBodySystem(pos.shape[0]) as s:
+        s.set_rows_per_lane(rpl)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step(1.0, eps)
+        return s.download()[1][:, :3]
+
+
+# ---- known answers -----------------------------------------------------------
+
+def test_unit_pair_known_answer(nb):
+    pos = np.array([[0, 0, 0, 1], [1, 0, 0, 1]], dtype=np.float32)
+    for eps in (0.0, 1e-3, 1e-2, 0.5):
+        a = gpu_accel(nb, pos, eps)
+        want = (1.0 + eps * eps) ** -1.5
+        assert a[0, 0] == pytest.approx(want, rel=1e-6) and a[1, 0] == pytest.approx(-want, rel=1e-6)
+        assert np.all(a[:, 1:] == 0)
+
+
+def test_coincident_bodies_and_zero_softening(nb):
+    pos = np.array([[0.5, 0.5, 0.5, 1.0], [0.5, 0.5, 0.5, 2.0], [1.5, 0.5, 0.5, 4.0]], dtype=np.float32)
+    for eps in (0.0, 1e-3):
+        a = gpu_accel(nb, pos, eps)
+        assert np.all(np.isfinite(a))
+        assert a[0, 0] == pytest.approx(4.0 / (1 + eps * eps) ** 1.5, rel=1e-6)
+        assert np.array_equal(a[0], a[1])
+
+
+def test_empty_and_single_body(nb):
+    p, v = run_gpu(nb, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), 1e-3, 1e-3, 2)
+    assert p.shape == (0, 4) and v.shape == (0, 4)
+    pos = np.array([[1, 2, 3, 5]], dtype=np.float32)
+    vel = np.array([[1, 0, 0, 9]], dtype=np.float32)
+    p, v = run_gpu(nb, pos, vel, 0.5, 1e-3, 2)
+    assert np.array_equal(p, np.array([[2, 2, 3, 5]], np.float32)) and np.array_equal(v, vel)
+
+
+# ---- accelerations and steps against the oracle ------------------------------------------------------
+
+@pytest.mark.parametrize("n", [2, 63, 255, 256, 257, 1000, 4097, 20000])
+def test_one_step_matches_oracle_ragged_sizes(nb, oracle_mod, n):
+    pos, vel = nb.uniform_cube(n, seed=100 + n, random_masses=True, speed=0.2)
+    a = gpu_accel(nb, pos, 1e-3)
+    a64 = oracle_mod.accel_f64(pos, eps=1e-3)
+    assert np.linalg.norm(a - a64) / np.linalg.norm(a64) < TOL
+    p, v = run_gpu(nb, pos, vel, 1e-3, 1e-3, 3)
+    pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=3)
+    assert rel_state_error(p, pr) < TOL and rel_state_error(v, vr) < TOL
+    assert np.array_equal(p[:, 3], pos[:, 3]) and np.array_equal(v[:, 3], vel[:, 3])  # mass / vel.w untouched
+
+
+def test_gpu_is_no_worse_than_reference_order_fp32(nb, oracle_mod):
+    pos, _ = nb.plummer(8192, seed=77)
+    a64 = oracle_mod.accel_f64(pos, eps=1e-3)
+    e_gpu = np.linalg.norm(gpu_accel(nb, pos, 1e-3) - a64) / np.linalg.norm(a64)
+    e_ref = np.linalg.norm(oracle_mod.accel_f32(pos, eps=1e-3) - a64) / np.linalg.norm(a64)
+    assert e_gpu < TOL and e_gpu < 4 * e_ref + 1e-7
+
+
+def test_config2_n65536_ten_steps(nb, oracle_mod):
+    """BASELINE.json configs[1]: N = 65 536 fp32, LDS tile 256, final state vs CPU within 1e-5 rel."""
+    pos, vel = nb.plummer(65536, seed=nb.CONFIG_SEED[2])
+    p, v = run_gpu(nb, pos, vel, 1e-3, 1e-3, 10)
+    pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=10)
+    assert rel_state_error(p, pr) < TOL and rel_state_error(v, vr) < TOL
+
+
+def test_golden_fixtures(nb, golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "f1_*.npz")))
+    assert len(files) >= 4
+    for f in files:
+        g = np.load(f)
+        for k in g["steps"]:
+            p, v = run_gpu(nb, g["pos0"], g["vel0"], float(g["dt"]), float(g["softening"]), int(k))
+            tol = TOL if k <= 10 else 5e-5  # 100 steps of a chaotic system: rounding differences grow
+            assert rel_state_error(p, g[f"p64_{k}"]) < tol and rel_state_error(v, g[f"v64_{k}"]) < tol, (f, k)
+            assert rel_state_error(p, g[f"p32_{k}"]) < tol, (f, k)
+
+
+def test_reference_constants_and_padding(nb, oracle_mod):
+    """The reference's own configuration: dt = 0.008, VERSION 3 softening, roundup(n,256)+1 zero-mass padding."""
+    pos, vel = nb.plummer(3000, seed=5)
+    ppos, pvel = nb.pad_reference_style(pos, vel)
+    p, v = run_gpu(nb, pos, vel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 5)
+    pp, vp = run_gpu(nb, ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 5)
+    n = pos.shape[0]
+    # padding bodies sit at the origin with zero mass: real bodies' results are unchanged to rounding
+    # (not bit-exact: the split boundaries depend on n_total)
+    assert rel_state_error(pp[:n], p) < 1e-6 and rel_state_error(vp[:n], v) < 1e-6
+    p3, v3 = oracle_mod.step_v3(ppos, pvel, nsteps=5)
+    assert rel_state_error(pp[:n], p3[:n]) < TOL and rel_state_error(vp[:n], v3[:n]) < TOL
+
+
+# ---- bit-exact invariances -----------------------------------------------------------------------
+
+def test_register_blocking_is_bit_exact(nb):
+    pos, vel = nb.plummer(10000, seed=31)
+    ref = None
+    for rpl in (1, 2, 4, 8):
+        with nb.NBodySystem(pos.shape[0]) as s:
+            s.set_rows_per_lane(rpl)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            s.step_n(2, 1e-3, 1e-3)
+            out = s.download()
+        if ref is None:
+            ref = out
+        assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]), rpl
+
+
+def test_row_shards_and_column_ranges_are_bit_exact(nb):
+    """P logical shards on one device, columns fed chunk by chunk in a rotated order: same bits as one context."""
+    import torch
+    n, P, steps = 8192, 4, 3
+    pos, vel = nb.plummer(n, seed=32)
+    split = 512                       # 16 splits; shard = 2048 rows = 4 splits
+    with nb.NBodySystem(n, split_len=split) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(steps, 1e-3, 1e-3)
+        want_p, want_v = s.download()
+    chunk = n // P
+    shards = [nb.NBodySystem(n, row_lo=r * chunk, row_count=chunk, split_len=split) for r in range(P)]
+    replica = torch.from_numpy(pos).cuda()
+    for r, s in enumerate(shards):
+        s.setParticlesVelocity(vel)
+    for _ in range(steps):
+        new = replica.clone()
+        for r, s in enumerate(shards):
+            for h in range(P):  # own chunk first, then the ring order a rank would receive them in
+                c = (r - h) % P
+                s.forces(c * chunk, chunk, 1e-3, positions=replica)
+            s.update(1e-3, positions=new)   # writes rows of shard r only
+            s.sync()
+        # "all-gather": every shard's rows were written into `new` from the old replica
+        upd = replica.clone()
+        for r in range(P):
+            upd[r * chunk:(r + 1) * chunk] = new[r * chunk:(r + 1) * chunk]
+        replica = upd
+    got_v = np.concatenate([s.velocities.cpu().numpy() for s in shards])
+    assert np.array_equal(replica.cpu().numpy(), want_p) and np.array_equal(got_v, want_v)
+    for s in shards:
+        s.close()
+
+
+def test_update_refuses_missing_column_ranges(nb):
+    pos, vel = nb.plummer(2048, seed=3)
+    with nb.NBodySystem(2048, split_len=256) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.forces(0, 1024, 1e-3)
+        with pytest.raises(nb.NBodyError):
+            s.update(1e-3)
+        with pytest.raises(nb.NBodyError):
+            s.forces(100, 256, 1e-3)       # not split-aligned
+        s.forces(1024, 1024, 1e-3)
+        s.update(1e-3)
+        s.sync()
+
+
+# ---- the call surface ------------------------------------------------------------------------------
+
+def test_functional_step_and_separate_masses(nb, oracle_mod):
+    import torch
+    pos, vel = nb.uniform_cube(1500, seed=8, random_masses=True, speed=0.1)
+    masses = pos[:, 3].copy()
+    scrambled = pos.copy()
+    scrambled[:, 3] = 123.0                      # mass must come from the masses argument
+    dp, dv = torch.from_numpy(scrambled).cuda(), torch.from_numpy(vel).cuda()
+    nb.step(dp, dv, torch.from_numpy(masses).cuda(), 1e-3, 1e-3)
+    pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=1)
+    assert rel_state_error(dp.cpu().numpy(), pr) < TOL and rel_state_error(dv.cpu().numpy(), vr) < TOL
+    assert np.array_equal(dp.cpu().numpy()[:, 3], masses)
+    dp2, dv2 = torch.from_numpy(pos).cuda(), torch.from_numpy(vel).cuda()
+    nb.step(dp2, dv2, None, 1e-3, 1e-3)          # masses=None: mass is positions[:,3] (the reference's layout)
+    assert torch.equal(dp, dp2) and torch.equal(dv, dv2)
+
+
+def test_c_abi_owned_buffers_without_torch_tensors(nb, oracle_mod):
+    """The path a C/C++ host takes: create, set_positions/velocities (host arrays), step_n, download."""
+    from n_body_problem_amd import _lib
+    lib = _lib.load()
+    pos, vel = nb.plummer(5000, seed=14)
+    ctx = ctypes.c_void_p(None)
+    assert lib.nbody_create(ctypes.byref(ctx), 0, 5000) == 0
+    assert lib.nbody_step_n(ctx, 1, 1e-3, 1e-3) == -5            # buffers never set
+    assert b"nbody_set_positions" in lib.nbody_last_error(ctx)
+    assert lib.nbody_set_positions(ctx, pos.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert lib.nbody_set_velocities(ctx, vel.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert lib.nbody_positions_device(ctx) and lib.nbody_velocities_device(ctx)
+    assert lib.nbody_step_n(ctx, 4, 1e-3, 1e-3) == 0
+    p, v = np.empty_like(pos), np.empty_like(vel)
+    assert lib.nbody_download(ctx, p.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert lib.nbody_destroy(ctx) == 0
+    pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=4)
+    assert rel_state_error(p, pr) < TOL and rel_state_error(v, vr) < TOL
+    p2, v2 = run_gpu(nb, pos, vel, 1e-3, 1e-3, 4)
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+
+
+def test_bad_arguments(nb):
+    with nb.NBodySystem(512) as s:
+        with pytest.raises(nb.NBodyError):
+            s.step(1e-3, -1.0)
+        with pytest.raises(nb.NBodyError):
+            s.step(float("nan"), 1e-3)
+        with pytest.raises(ValueError):
+            s.setParticlesPosition(np.zeros((5, 4), np.float32))
+
+
+# ---- diagnostics -----------------------------------------------------------------------------------
+
+def test_energy_and_momentum_match_oracle(nb, oracle_mod):
+    pos, vel = nb.plummer(6000, seed=15)
+    with nb.NBodySystem(6000) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        e = s.energy(1e-3)
+        m = s.momentum()
+    assert np.allclose(e, oracle_mod.energy(pos, vel, 1e-3), rtol=1e-6)
+    mo = oracle_mod.momentum(pos, vel)
+    assert np.allclose(m, mo, rtol=1e-9, atol=1e-12)
+
+
+def test_energy_drift_over_200_steps(nb):
+    pos, vel = nb.plummer(16384, seed=16)
+    with nb.NBodySystem(16384) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        e0 = s.energy(1e-2)
+        s.step_n(200, 1e-3, 1e-2)
+        e1 = s.energy(1e-2)
+        m1 = s.momentum()
+    assert abs(e1[2] - e0[2]) / abs(e0[2]) < 1e-4
+    assert np.abs(m1[:3]).max() < 1e-5
+
+
+# ---- BASELINE.json's full size, through size-independent properties ----------------------------------
+
+def test_full_size_n1048576_properties(nb, oracle_mod):
+    """N = 2^20 (configs[2]): one step; (1) a sample of rows vs the fp64 oracle, (2) sum_i m_i a_i = 0
+    (Newton's third law over all 1.1e12 ordered pairs), (3) the state update is the oracle's kick-drift."""
+    n = 1 << 20
+    pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
+    with nb.NBodySystem(n) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(np.zeros_like(vel))
+        s.step(1.0, 1e-3)                     # v_new = a
+        acc = s.download()[1][:, :3].astype(np.float64)
+    rows = np.concatenate([np.arange(0, 256), np.arange(n // 2 - 128, n // 2 + 128), np.arange(n - 256, n)])
+    for lo, hi in ((0, 256), (n // 2 - 128, n // 2 + 128), (n - 256, n)):
+        a64 = oracle_mod.accel_f64(pos, i0=lo, i1=hi, eps=1e-3)
+        assert np.linalg.norm(acc[lo:hi] - a64) / np.linalg.norm(a64) < TOL
+    assert rows.size == 768
+    m = pos[:, 3].astype(np.float64)
+    net = (m[:, None] * acc).sum(0)
+    scale = (m[:, None] * np.abs(acc)).sum(0)
+    assert np.all(np.abs(net) < 1e-5 * scale)
