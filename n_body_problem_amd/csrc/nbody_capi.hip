@@ -330,14 +330,15 @@ int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
     return NBODY_OK;
 }
 
-// Largest register blocking that still leaves every CU several workgroups.  Speed only: each
-// row's sum is the same FMA chain whatever the blocking.
+// Largest register blocking that still leaves every CU several workgroups (8 rows per lane measured
+// fastest at N = 2^20: one broadcast LDS read feeds 8 interactions).  Speed only: each row's sum is the
+// same FMA chain whatever the blocking.
 static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
 {
     if (c->rows_per_lane)
         return c->rows_per_lane;
     const int64_t want = 4LL * c->cu_count;
-    for (int rpl : {4, 2}) {
+    for (int rpl : {8, 4, 2}) {
         int64_t blocks = (c->row_count + (int64_t)kTile * rpl - 1) / ((int64_t)kTile * rpl) * split_count;
         if (blocks >= want)
             return rpl;

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag>/ directory (written by tools/profile.sh on the GPU box) into the
+tracked summaries under profiles/:  <round>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats) and
+<round>_pmc_n<N>.json (per-launch PMC counters of nbody::force_kernel with the gfx950 corrections of
+MI355X_MICROARCH.md: FETCH_SIZE is in KiB and reads HALF the bytes of a 16-B/lane coalesced stream)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(tag, rnd, n):
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+    out = {"n": n, "round": rnd, "kernel": "nbody::force_kernel", "source": f"tools/profile.sh {tag} (rocprofv3, separate --pmc passes)"}
+    counters = defaultdict(list)
+    durations = []
+    vgpr = None
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if "force_kernel" in r["Kernel_Name"]:
+                    counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    vgpr = r.get("VGPR_Count")
+                    out["kernel_name"] = r["Kernel_Name"]
+                    out["lds_block_size"] = int(r["LDS_Block_Size"])
+    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            if "force_kernel" in r["Kernel_Name"]:
+                durations.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    mean = {k: sum(v) / len(v) for k, v in counters.items()}
+    out["counters_per_launch"] = mean
+    out["avg_launch_ms_kernel_trace"] = sum(durations) / len(durations) if durations else None
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        fetch = mean["FETCH_SIZE"] * 1024.0 * 2.0   # KiB -> B, x2: gfx950 counts 128-B requests as 64 B
+        write = mean["WRITE_SIZE"] * 1024.0
+        out["hbm_read_bytes_per_force_launch"] = fetch
+        out["hbm_write_bytes_per_force_launch"] = write
+        out["hbm_bytes_per_force_launch"] = fetch + write
+        if durations:
+            out["hbm_GBps"] = (fetch + write) / (out["avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
+    if "GRBM_GUI_ACTIVE" in mean and durations:
+        cyc = mean["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
+        out["effective_clock_GHz"] = cyc / (out["avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
+        if "SQ_ACTIVE_INST_VALU" in mean:
+            out["valu_busy_fraction"] = mean["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)   # quad-cycles, 1024 SIMDs
+        if "SQ_WAVE_CYCLES" in mean:
+            out["mean_waves_per_simd"] = mean["SQ_WAVE_CYCLES"] * 4.0 / (cyc * 1024.0)
+        if "SQ_INSTS_VALU" in mean:
+            inter = float(n) * float(n) / 64.0
+            out["valu_instructions_per_interaction"] = mean["SQ_INSTS_VALU"] / inter
+            out["simd_cycles_per_interaction"] = cyc * 1024.0 / inter
+    out["vgpr_count_reported"] = vgpr
+    path = os.path.join(dst, f"{rnd}_pmc_n{n}.json")
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20)

@@ -16,6 +16,7 @@ static const char *kNames[] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_pk_m
                                "ds_read_b128 bcast", "mix 52 valu + 4 rsq + 1 ds_read", ""};
 // wave-instructions issued per loop iteration, and interactions they stand for
 static const int kInstr[] = {8, 8, 8, 8, 8, 8, 8, 8, 13, 8, 8, 57, 0};
+constexpr int kRep = 8;
 
 template <int OP>
 __global__ __launch_bounds__(256) void bench(float *out, unsigned long long *cycles, int iters, float seed, float sarg)
@@ -33,8 +34,11 @@ __global__ __launch_bounds__(256) void bench(float *out, unsigned long long *cyc
     const f2 pb = f2{0.999f, 0.998f}, pc = f2{0.001f, 0.002f};
     float4 q = make_float4(0, 0, 0, 0);
     unsigned laddr = 0;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int rep = 0; rep < kRep; ++rep) {  // straight-line repeats: loop overhead < 1 %
         if (OP == FMA) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
@@ -114,13 +118,18 @@ __global__ __launch_bounds__(256) void bench(float *out, unsigned long long *cyc
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n v_add_f32 %0, %0, %1" : "+v"(q.x) : "v"(r.x));
         }
+      }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = q.x;
     for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0)
-        cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    {
+        cycles[2 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)] = t1 - t0;
+        cycles[2 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) + 1] = r1 - r0;  // 100 MHz ticks
+    }
 }
 
 template <int OP>
@@ -138,15 +147,17 @@ static void run(int cus, int waves_per_simd, int iters, float *out, unsigned lon
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const int nw = blocks * 4;
-    hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost);
-    std::sort(h.begin(), h.begin() + nw);
-    const double med = (double)h[nw / 2];
-    const double instr_per_wave = (double)iters * kInstr[OP];
-    const double cyc_per_instr = med * waves_per_simd / instr_per_wave / waves_per_simd;  // per wave
-    const double simd_cyc_per_instr = med / (instr_per_wave * waves_per_simd);           // per SIMD issue slot
-    const double ghz = med / (ms * 1e6);
-    printf("%-34s waves/SIMD=%d  wave-cycles/instr=%6.2f  SIMD-cycles/instr=%6.3f  kernel=%8.3f ms  clk~%.2f GHz\n",
-           kNames[OP], waves_per_simd, cyc_per_instr, simd_cyc_per_instr, ms, ghz);
+    hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * nw * 2, hipMemcpyDeviceToHost);
+    std::vector<double> cy(nw), rt(nw);
+    for (int i = 0; i < nw; ++i) { cy[i] = (double)h[2 * i]; rt[i] = (double)h[2 * i + 1]; }
+    std::sort(cy.begin(), cy.end());
+    std::sort(rt.begin(), rt.end());
+    const double med = cy[nw / 2], med_ns = rt[nw / 2] * 10.0;  // s_memrealtime: 100 MHz
+    const double instr_per_wave = (double)iters * kRep * kInstr[OP];
+    const double ghz = med / med_ns;
+    printf("%-34s w/SIMD=%d  wave: %6.2f cyc/instr  SIMD: %6.3f cyc/instr %6.3f ns/instr  wave-time %7.3f ms kernel %7.3f ms  shader clk %.2f GHz\n",
+           kNames[OP], waves_per_simd, med / instr_per_wave, med / (instr_per_wave * waves_per_simd),
+           med_ns / (instr_per_wave * waves_per_simd), med_ns * 1e-6, ms, ghz);
     hipEventDestroy(e0);
     hipEventDestroy(e1);
 }
@@ -164,9 +175,9 @@ int main()
     float *out;
     unsigned long long *cyc;
     hipMalloc((void **)&out, sizeof(float) * max_blocks * 256);
-    hipMalloc((void **)&cyc, sizeof(unsigned long long) * max_blocks * 4);
-    std::vector<unsigned long long> h(max_blocks * 4);
-    const int iters = 20000;
+    hipMalloc((void **)&cyc, sizeof(unsigned long long) * max_blocks * 8);
+    std::vector<unsigned long long> h(max_blocks * 8);
+    const int iters = 4000;
     for (int w : {1, 2, 4, 8}) {
         run<FMA>(cus, w, iters, out, cyc, h);
         run<PK_FMA>(cus, w, iters, out, cyc, h);
