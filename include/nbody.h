@@ -54,7 +54,8 @@ const char *nbody_status_string(int status);
  * nbody_create      : all n_total bodies are rows and columns of this context (one GPU).
  * nbody_create_shard: the context integrates rows [row_lo, row_lo+row_count) against all n_total
  *                     columns (one rank of a multi-GPU run).  split_len = columns per partial sum,
- *                     a multiple of 256, 0 = nbody_default_split_len(n_total); row_lo must be a
+ *                     a multiple of 256, 0 = nbody_default_split_len(n_total) (8192 columns for
+ *                     131072 <= n_total <= 1048576, else n_total/16 or n_total/128); row_lo must be a
  *                     multiple of split_len so that shard boundaries never cut a split.
  * The context owns the acceleration partials (the reference's gravity_sum_array), a stream and, on
  * demand, position/velocity buffers.  n_total need not be padded; the reference's roundup(n,256)+1
@@ -105,6 +106,10 @@ int nbody_sync(nbody_ctx *ctx);
  *   use_acc_update_position (kernel.cu:777-801) to this context's rows.  Asynchronous.
  * Every split must have been produced by nbody_forces since the previous nbody_update. */
 int nbody_forces(nbody_ctx *ctx, const float *d_positions_xyzm, int64_t col_lo, int64_t col_count, float softening);
+/* The same for every column EXCEPT [col_lo, col_lo+col_count), in one launch: what a rank runs once the
+ * exchange has delivered the other ranks' rows, its own column chunk having been done beside the exchange. */
+int nbody_forces_complement(nbody_ctx *ctx, const float *d_positions_xyzm, int64_t col_lo, int64_t col_count,
+                            float softening);
 int nbody_update(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, float dt);
 
 /* Run on the caller's HIP stream (a hipStream_t passed as void*); NULL restores the context's own stream. */

@@ -47,6 +47,7 @@ _PROTOTYPES = {
     "nbody_step_n": (c_int, [c_void_p, c_int, c_float, c_float]),
     "nbody_sync": (c_int, [c_void_p]),
     "nbody_forces": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
+    "nbody_forces_complement": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "nbody_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float]),
     "nbody_set_stream": (c_int, [c_void_p, c_void_p]),
     "nbody_energy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, POINTER(c_double)]),

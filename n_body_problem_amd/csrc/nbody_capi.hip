@@ -74,11 +74,20 @@ const char *nbody_last_error(const nbody_ctx *ctx) { return ctx ? ctx->err.c_str
 
 int64_t nbody_default_split_len(int64_t n_total)
 {
-    // 16 splits of the columns, rounded up to whole 256-body tiles.  A function of n_total ONLY:
-    // split boundaries define the summation order, so they must not depend on the sharding.
+    // Columns per partial sum.  A function of n_total ONLY: split boundaries define the summation order, so
+    // they must not depend on the sharding.  8192 columns (32 LDS tiles) per split while that gives 16..128
+    // splits; outside that range the split count is pinned to 16 (small N) or 128 (large N).  Many splits
+    // keep the grid fine-grained when 8 ranks share N = 2^20 (each rank: 64 row tiles x 128 splits).
     if (n_total <= 0)
         return kTile;
-    int64_t len = (n_total + 15) / 16;
+    const int64_t target = 8192;
+    int64_t len;
+    if (n_total < 16 * target)
+        len = (n_total + 15) / 16;
+    else if (n_total <= 128 * target)
+        len = target;
+    else
+        len = (n_total + 127) / 128;
     return (len + kTile - 1) / kTile * kTile;
 }
 
@@ -346,18 +355,20 @@ static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
     return 1;
 }
 
-int nbody_forces(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t col_count, float softening)
+static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t col_count, float softening,
+                       bool complement, const char *who)
 {
     if (!c || (!d_pos && c->n_total))
-        return fail(c, NBODY_ERR_INVALID, "nbody_forces: NULL argument");
+        return fail(c, NBODY_ERR_INVALID, std::string(who) + ": NULL argument");
     if (!(softening >= 0.f) || !std::isfinite(softening))
-        return fail(c, NBODY_ERR_INVALID, "nbody_forces: softening must be finite and >= 0");
+        return fail(c, NBODY_ERR_INVALID, std::string(who) + ": softening must be finite and >= 0");
     if (col_lo < 0 || col_count < 0 || col_lo + col_count > c->n_total || col_lo % c->split_len != 0 ||
         ((col_lo + col_count) % c->split_len != 0 && col_lo + col_count != c->n_total))
-        return fail(c, NBODY_ERR_INVALID, "nbody_forces: column range must be split-aligned and inside [0,n_total]");
-    if (col_count == 0 || c->row_count == 0)
+        return fail(c, NBODY_ERR_INVALID, std::string(who) + ": column range must be split-aligned and inside [0,n_total]");
+    if (c->row_count == 0 || c->n_total == 0)
         return NBODY_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
+    const int first = (int)(col_lo / c->split_len);
+    const int count = (int)((col_count + c->split_len - 1) / c->split_len);
     ForceArgs a;
     a.pos = reinterpret_cast<const float4 *>(d_pos);
     a.partials = c->partials;
@@ -365,16 +376,39 @@ int nbody_forces(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t col_c
     a.row_count = (int)c->row_count;
     a.n_total = (int)c->n_total;
     a.split_len = (int)c->split_len;
-    a.split_first = (int)(col_lo / c->split_len);
-    a.split_count = (int)((col_count + c->split_len - 1) / c->split_len);
     a.eps2 = softening * softening;
+    if (complement) {  // every split except [first, first+count)
+        a.split_first = 0;
+        a.split_count = c->n_splits - count;
+        a.skip_first = first;
+        a.skip_count = count;
+    } else {
+        a.split_first = first;
+        a.split_count = count;
+        a.skip_first = c->n_splits;  // never reached
+        a.skip_count = 0;
+    }
+    if (a.split_count <= 0)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
     {
         TimedLaunch t(c, &c->ev_force);
         HIP_TRY(c, launch_forces(a, pick_rows_per_lane(c, a.split_count), c->stream));
     }
-    for (int s = 0; s < a.split_count; ++s)
-        c->split_done[(size_t)(a.split_first + s)] = 1;
+    for (int s = 0; s < c->n_splits; ++s)
+        if ((s >= first && s < first + count) != complement)
+            c->split_done[(size_t)s] = 1;
     return NBODY_OK;
+}
+
+int nbody_forces(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t col_count, float softening)
+{
+    return forces_impl(c, d_pos, col_lo, col_count, softening, false, "nbody_forces");
+}
+
+int nbody_forces_complement(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t col_count, float softening)
+{
+    return forces_impl(c, d_pos, col_lo, col_count, softening, true, "nbody_forces_complement");
 }
 
 int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)

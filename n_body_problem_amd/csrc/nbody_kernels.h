@@ -17,6 +17,8 @@ struct ForceArgs {
     int split_len;       // columns per split (multiple of kTile)
     int split_first;     // first split computed by this launch
     int split_count;     // splits computed by this launch (grid.y)
+    int skip_first;      // splits [skip_first, skip_first+skip_count) are stepped over (a launch that covers
+    int skip_count;      //   "every split except a range": split = split_first + y, += skip_count once >= skip_first
     float eps2;          // softening length squared
 };
 

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     __shared__ float4 tile[2][kTile];
 
     const int tid = threadIdx.x;
-    const int split = a.split_first + blockIdx.y;
+    int split = a.split_first + blockIdx.y;
+    if (split >= a.skip_first)
+        split += a.skip_count;
     const int j0 = split * a.split_len;
     const int j1 = min(j0 + a.split_len, a.n_total);
     const int ntiles = (j1 - j0 + kTile - 1) / kTile;

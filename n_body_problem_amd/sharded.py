@@ -44,8 +44,8 @@ class ShardedNBodySystem:
     """The reference's step interface (see :mod:`n_body_problem_amd.system`) for one rank of a sharded run.
 
     ``kernels_factory(n_padded, row_lo, row_count, split_len)`` must return an object with the interface of
-    :class:`NBodySystem` (``positions``, ``velocities``, ``forces``, ``update``, ``sync``, ``energy``,
-    ``momentum``).  The default -- and the only one the package ships -- is the HIP-backed ``NBodySystem``;
+    :class:`NBodySystem` (``positions``, ``velocities``, ``forces``, ``forces_complement``, ``update``, ``sync``,
+    ``energy``, ``momentum``).  The default -- and the only one the package ships -- is the HIP-backed ``NBodySystem``;
     tests inject a CPU stand-in to exercise the sharding and exchange logic under ``gloo``.
     """
 
@@ -79,8 +79,12 @@ class ShardedNBodySystem:
         self.positions = self.kernels.positions      # full replica, (n_padded, 4)
         self.velocities = self.kernels.velocities    # own rows, (chunk, 4)
         self._on_gpu = bool(self.positions.is_cuda)
-        self._send = None if self._on_gpu else torch.empty_like(self.positions[:self.chunk])
+        backend = dist.get_backend(group) if self.distributed else "none"
+        # RCCL gathers in place; other backends (gloo in the tests) get a staging copy of the own chunk
+        self._inplace = self._on_gpu and backend == "nccl"
+        self._send = None if self._inplace else torch.empty_like(self.positions[:self.chunk])
         self._comm_stream = torch.cuda.Stream(device=self.positions.device) if self._on_gpu else None
+        self._side_stream = torch.cuda.Stream(device=self.positions.device) if self._on_gpu else None
         self._pending = None   # allgather mode: work handle of the exchange in flight
         self._stale = False    # ring mode: remote chunks of the replica are one update behind
 
@@ -128,7 +132,7 @@ class ShardedNBodySystem:
 
     def _start_allgather(self) -> None:
         dist = self._dist
-        if self._on_gpu:
+        if self._inplace:
             # in place: RCCL recognises sendbuff == recvbuff + rank*count and skips the self copy, so the
             # own chunk is never written while the next step's own-chunk force kernel reads it
             send = self._chunk(self.rank)
@@ -182,12 +186,22 @@ class ShardedNBodySystem:
                 k.forces(recv_c * self.chunk, self.chunk, softening)
             self._stale = False
         else:
+            torch = self._torch
+            two_streams = self._on_gpu and self.world_size > 1
+            if two_streams:
+                cur = torch.cuda.current_stream(self.positions.device)
+                self._side_stream.wait_stream(cur)           # uploads / the previous update are ordered before it
             k.forces(lo, self.chunk, softening)              # own chunk: runs beside the all-gather in flight
-            self._drain()
-            if lo > 0:
-                k.forces(0, lo, softening)
-            if hi < self.n_padded:
-                k.forces(hi, self.n_padded - hi, softening)
+            if two_streams:
+                # the other chunks on a second stream: their workgroups fill the CUs the first launch's tail
+                # leaves idle (the launches write disjoint partial sums)
+                with torch.cuda.stream(self._side_stream):
+                    self._drain()                            # this stream, not the host, waits for the exchange
+                    k.forces_complement(lo, self.chunk, softening)
+                cur.wait_stream(self._side_stream)
+            elif self.world_size > 1:
+                self._drain()
+                k.forces_complement(lo, self.chunk, softening)
         k.update(dt)
         if self.world_size > 1:
             if self.exchange == "allgather":

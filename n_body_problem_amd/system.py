@@ -145,6 +145,13 @@ class NBodySystem:
         p = self.positions if positions is None else positions
         check(self._lib.nbody_forces(self._ctx, _ptr(p), int(col_lo), int(col_count), float(softening)), self._ctx)
 
+    def forces_complement(self, col_lo: int, col_count: int, softening: float, positions=None) -> None:
+        """Partial accelerations from every column EXCEPT ``[col_lo, col_lo+col_count)``, one launch (async)."""
+        self._use_current_stream()
+        p = self.positions if positions is None else positions
+        check(self._lib.nbody_forces_complement(self._ctx, _ptr(p), int(col_lo), int(col_count), float(softening)),
+              self._ctx)
+
     def update(self, dt: float, positions=None, velocities=None) -> None:
         """Sum the partials of all splits and kick-drift this context's rows (async)."""
         self._use_current_stream()

@@ -27,12 +27,19 @@ class OracleKernels:
     def forces(self, col_lo, col_count, softening, positions=None):
         assert col_lo % self.L == 0 and ((col_lo + col_count) % self.L == 0 or col_lo + col_count == self.n)
         pos = self.positions.numpy()
-        self.calls.append((col_lo, col_count))
+        self.calls.append(("range", col_lo, col_count))
         for s in range(col_lo // self.L, -(-(col_lo + col_count) // self.L)):
             j0, j1 = s * self.L, min((s + 1) * self.L, self.n)
             assert s not in self.partials, "split computed twice in one step"
             self.partials[s] = self.oracle.accel_f32(pos, self.row_lo, self.row_lo + self.rows, j0, j1, softening,
                                                      threads=1)
+
+    def forces_complement(self, col_lo, col_count, softening, positions=None):
+        self.calls.append(("complement", col_lo, col_count))
+        if col_lo > 0:
+            self.forces(0, col_lo, softening)
+        if col_lo + col_count < self.n:
+            self.forces(col_lo + col_count, self.n - (col_lo + col_count), softening)
 
     def update(self, dt, positions=None, velocities=None):
         assert sorted(self.partials) == list(range(self.n_splits)), "a split is missing"
@@ -85,8 +92,32 @@ def run_rank(rank, world_size, port, exchange, n, split_len, steps, out_dir):
         e1 = s.energy(1e-2)
         mom = s.momentum()
         np.savez(os.path.join(out_dir, f"w{world_size}_{exchange}_r{rank}.npz"), p=p, v=v, e0=e0, e1=e1, mom=mom,
-                 calls=np.array(s.kernels.calls[-3:], dtype=np.int64), n_padded=s.n_padded, chunk=s.chunk)
+                 calls=np.array([c[1:] for c in s.kernels.calls if c[0] == "range"][-2:], dtype=np.int64),
+                 kinds=np.array([c[0] for c in s.kernels.calls]), n_padded=s.n_padded, chunk=s.chunk)
         s.close()
     finally:
         if world_size > 1:
             dist.destroy_process_group()
+
+
+def run_rank_gpu(rank, world_size, port, exchange, n, steps, out_dir):
+    """One rank of a sharded run with the REAL HIP kernels; all ranks share cuda:0, gloo carries the exchange."""
+    import torch
+    import torch.distributed as dist
+    from n_body_problem_amd import initial_conditions as ic
+    from n_body_problem_amd.sharded import ShardedNBodySystem
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
+    try:
+        pos, vel = ic.plummer(n, seed=4321)
+        s = ShardedNBodySystem(n, device=0, exchange=exchange)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(steps, 1e-3, 1e-3)
+        p, v = s.download()
+        e = s.energy(1e-3)
+        np.savez(os.path.join(out_dir, f"gpu_w{world_size}_{exchange}_r{rank}.npz"), p=p, v=v, e=e,
+                 n_padded=s.n_padded, chunk=s.chunk, split_len=s.split_len)
+        s.close()
+    finally:
+        dist.destroy_process_group()

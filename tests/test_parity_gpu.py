@@ -185,6 +185,24 @@ def test_row_shards_and_column_ranges_are_bit_exact(nb):
         s.close()
 
 
+def test_forces_complement_is_the_same_launch_set(nb):
+    pos, vel = nb.plummer(6000, seed=33)
+    outs = []
+    for mode in ("whole", "own+complement"):
+        with nb.NBodySystem(6000, split_len=512) as s:
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            if mode == "whole":
+                s.forces(0, 6000, 1e-3)
+            else:
+                s.forces(1024, 2048, 1e-3)
+                s.forces_complement(1024, 2048, 1e-3)
+            s.update(1e-3)
+            s.sync()
+            outs.append(s.download())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_update_refuses_missing_column_ranges(nb):
     pos, vel = nb.plummer(2048, seed=3)
     with nb.NBodySystem(2048, split_len=256) as s:
