@@ -112,8 +112,10 @@ int nbody_forces_complement(nbody_ctx *ctx, const float *d_positions_xyzm, int64
                             float softening);
 int nbody_update(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, float dt);
 
-/* Run on the caller's HIP stream (a hipStream_t passed as void*); NULL restores the context's own stream. */
+/* nbody_set_stream: enqueue on the caller's HIP stream (a hipStream_t passed as void*, used verbatim: NULL is
+ * the HIP default stream).  nbody_reset_stream: back to the context's own non-blocking stream (the default). */
 int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);
+int nbody_reset_stream(nbody_ctx *ctx);
 
 /* ---- diagnostics (the reference has none) ----
  * nbody_energy: out = {kinetic, potential, total} of this context's rows against all columns

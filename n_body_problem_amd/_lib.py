@@ -50,6 +50,7 @@ _PROTOTYPES = {
     "nbody_forces_complement": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "nbody_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float]),
     "nbody_set_stream": (c_int, [c_void_p, c_void_p]),
+    "nbody_reset_stream": (c_int, [c_void_p]),
     "nbody_energy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, POINTER(c_double)]),
     "nbody_momentum": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "nbody_timing_enable": (c_int, [c_void_p, c_int]),

@@ -189,7 +189,15 @@ int nbody_set_stream(nbody_ctx *c, void *hip_stream)
 {
     if (!c)
         return NBODY_ERR_INVALID;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;  // verbatim: NULL is the HIP default stream
+    return NBODY_OK;
+}
+
+int nbody_reset_stream(nbody_ctx *c)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    c->stream = c->own_stream;
     return NBODY_OK;
 }
 

@@ -149,18 +149,28 @@ class ShardedNBodySystem:
         """One hop: chunk send_c goes to rank+1 while chunk recv_c arrives from rank-1, in place in the replica.
         On return the CURRENT stream is ordered after the arrival; the hop itself runs on the comm stream."""
         torch, dist = self._torch, self._dist
-        ops = [dist.P2POp(dist.isend, self._chunk(send_c), self._peer(self.rank + 1), group=self.group),
-               dist.P2POp(dist.irecv, self._chunk(recv_c), self._peer(self.rank - 1), group=self.group)]
-        if self._on_gpu:
+        nxt, prv = self._peer(self.rank + 1), self._peer(self.rank - 1)
+        if self._inplace:  # RCCL: device buffers, ordered on the communication stream
+            ops = [dist.P2POp(dist.isend, self._chunk(send_c), nxt, group=self.group),
+                   dist.P2POp(dist.irecv, self._chunk(recv_c), prv, group=self.group)]
             with torch.cuda.stream(self._comm_stream):
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()  # orders the comm stream (not the host) after the transfer
                 landed = torch.cuda.Event()
                 landed.record(self._comm_stream)
             torch.cuda.current_stream(self.positions.device).wait_event(landed)
-        else:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            return
+        # any other backend (gloo in the tests): blocking, staged through host memory when the replica is on a GPU
+        if self._on_gpu:
+            self._comm_stream.synchronize()
+            torch.cuda.current_stream(self.positions.device).synchronize()
+        send = self._chunk(send_c).cpu() if self._on_gpu else self._chunk(send_c)
+        recv = torch.empty_like(send) if self._on_gpu else self._chunk(recv_c)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, nxt, group=self.group),
+                                         dist.P2POp(dist.irecv, recv, prv, group=self.group)]):
+            w.wait()
+        if self._on_gpu:
+            self._chunk(recv_c).copy_(recv)
 
     def _refresh(self) -> None:
         """Bring every chunk of the replica up to date without computing anything."""
