@@ -76,13 +76,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="bodies (BASELINE.json: 2^20)")
+    ap.add_argument("--n", "--bodies", dest="n", type=int, default=1 << 20, help="bodies (BASELINE.json: 2^20)")
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--softening", type=float, default=1e-3)
     ap.add_argument("--exchange", default=os.environ.get("NBODY_EXCHANGE", "allgather"), choices=["allgather", "ring"])
     ap.add_argument("--rows-per-lane", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the product path); gloo only to rehearse the multi-rank flow on one GPU")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -97,9 +100,14 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     n = args.n
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
@@ -164,6 +172,7 @@ def main():
                                    f"softening={args.softening}, dt={args.dt}, LDS tile=256",
                        "n_bodies": n, "parallelism": f"rows sharded x{world}" if world > 1 else "1 GPU",
                        "exchange": args.exchange if world > 1 else None,
+                       "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
                        "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3]},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,

@@ -1,0 +1,109 @@
+// nbody_run.cpp -- thin C++ host over the C ABI: the reference's main loop (main_project/kernel.cu:1067-1295)
+// without the window.  Load or generate bodies, initialize(), setParticlesPosition/Velocity(), then one
+// step() per "frame"; instead of drawing, it reports timing, energy and momentum and can dump / resume raw
+// snapshots (the reference keeps its state only in the VBO).
+//
+//   nbody_run [dataset_id]                               the reference's CLI (kernel.cu:1069-1086), files in --data-dir
+//   nbody_run --plummer 65536 --steps 100 --dt 1e-3 --softening 1e-3 --energy-every 10
+//   nbody_run --file galaxy.bin --steps 1000 --dump-every 100 --dump-prefix out/gal
+//   nbody_run --resume out/gal_000500.nbs --steps 500
+//
+// Build: g++ -O2 -std=c++17 -Iinclude host/nbody_run.cpp -Ln_body_problem_amd -lnbody_amd -Wl,-rpath,'$ORIGIN/../n_body_problem_amd'
+#include "../include/nbody.hpp"
+#include "nbody_io.hpp"
+
+#include <chrono>
+#include <cstdlib>
+#include <iostream>
+
+static void usage()
+{
+    std::cerr << "usage: nbody_run [dataset_id 0-5] [--data-dir DIR] [--file PATH] [--plummer N] [--seed S] [--resume SNAPSHOT]\n"
+                 "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P]\n"
+                 "                 [--pad-reference] [--device D] [--final SNAPSHOT]\n";
+}
+
+int main(int argc, char **argv)
+{
+    int dataset = -1, device = 0;
+    std::string data_dir = "./data", file, resume, dump_prefix = "nbody", final_path;
+    std::int64_t plummer_n = 0, steps = 100, energy_every = 0, dump_every = 0;
+    std::uint64_t seed = 0x5EED0003ull;
+    float dt = nbody::kTimeTick, softening = nbody::kSofteningVersion3;  // the reference's constants
+    bool pad = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
+        if (a == "--data-dir") data_dir = next();
+        else if (a == "--file") file = next();
+        else if (a == "--plummer") plummer_n = std::atoll(next().c_str());
+        else if (a == "--seed") seed = std::strtoull(next().c_str(), nullptr, 0);
+        else if (a == "--resume") resume = next();
+        else if (a == "--steps") steps = std::atoll(next().c_str());
+        else if (a == "--dt") dt = (float)std::atof(next().c_str());
+        else if (a == "--softening") softening = (float)std::atof(next().c_str());
+        else if (a == "--energy-every") energy_every = std::atoll(next().c_str());
+        else if (a == "--dump-every") dump_every = std::atoll(next().c_str());
+        else if (a == "--dump-prefix") dump_prefix = next();
+        else if (a == "--final") final_path = next();
+        else if (a == "--pad-reference") pad = true;
+        else if (a == "--device") device = std::atoi(next().c_str());
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (!a.empty() && a[0] != '-') {
+            dataset = std::atoi(a.c_str());  // kernel.cu:1069-1086: argv[1] = dataset id, 0..5
+            if (dataset < 0 || dataset > 5) { std::cerr << "dataset id must be 0..5\n"; return 2; }
+        } else { usage(); return 2; }
+    }
+    try {
+        nbody_io::Bodies b;
+        std::int64_t step0 = 0;
+        double time0 = 0.0;
+        if (!resume.empty()) b = nbody_io::load_snapshot(resume, &step0, &time0);
+        else if (!file.empty()) b = nbody_io::read_any(file);
+        else if (dataset >= 0) b = nbody_io::read_any(data_dir + "/" + nbody_io::reference_dataset(dataset));
+        else b = nbody_io::plummer(plummer_n > 0 ? plummer_n : 65536, seed);
+        const std::int64_t n_real = b.n();
+        if (pad) nbody_io::pad_reference_style(b);  // accepted, never required (kernel.cu:260-278)
+        std::printf("num of Bodies = %lld (real %lld)  dt = %g  softening = %g\n", (long long)b.n(), (long long)n_real, dt, softening);
+
+        nbody::System sys(b.n(), device);               // initialize(numBodies)
+        sys.setParticlesPosition(b.pos.data());
+        sys.setParticlesVelocity(b.vel.data());
+        sys.timing(true);
+        nbody::System::Energy e0{};
+        if (energy_every > 0) {
+            e0 = sys.energy(softening);
+            std::printf("step %lld  E = %.9e (K %.6e U %.6e)\n", (long long)step0, e0.total, e0.kinetic, e0.potential);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (std::int64_t s = 1; s <= steps; ++s) {
+            sys.step(dt, softening);                    // the bracket kernel.cu:1225-1242
+            const std::int64_t gs = step0 + s;
+            if (energy_every > 0 && (s % energy_every == 0 || s == steps)) {
+                auto e = sys.energy(softening);
+                auto p = sys.momentum();
+                std::printf("step %lld  E = %.9e  dE/E0 = %+.3e  |p| = %.3e\n", (long long)gs, e.total, (e.total - e0.total) / std::fabs(e0.total),
+                            std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+            }
+            if (dump_every > 0 && s % dump_every == 0) {
+                sys.download(b.pos.data(), b.vel.data());
+                char name[512];
+                std::snprintf(name, sizeof name, "%s_%06lld.nbs", dump_prefix.c_str(), (long long)gs);
+                nbody_io::save_snapshot(name, b, gs, time0 + (double)s * dt);
+            }
+        }
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        auto tm = sys.readTiming();
+        const double inter = (double)b.n() * (double)b.n() * (double)steps;
+        std::printf("%lld steps in %.3f s: %.3f ms/step, %.3e interactions/s (force kernels %.3f ms/step, update %.3f ms/step)\n",
+                    (long long)steps, wall, 1e3 * wall / (double)steps, inter / wall, tm.forceMs / (double)steps, tm.updateMs / (double)steps);
+        if (!final_path.empty()) {
+            sys.download(b.pos.data(), b.vel.data());
+            nbody_io::save_snapshot(final_path, b, step0 + steps, time0 + (double)steps * dt);
+        }
+    } catch (const std::exception &ex) {
+        std::cerr << "nbody_run: " << ex.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,106 @@
+// nbody.hpp -- header-only C++ convenience layer over the C ABI of nbody.h.
+//
+// Keeps the names of the reference's host interface for this path (main_project/kernel.cu):
+//   initialize(numBodies)            :130-161      -> nbody::System::initialize / constructor
+//   setParticlesPosition(real*)      :163-177      -> System::setParticlesPosition
+//   setParticlesVelocity(real*)      :179-188      -> System::setParticlesVelocity
+//   the per-frame bracket            :1225-1242    -> System::step(dt, softening)
+// so that the reference's main loop reads the same after the swap.  Errors become
+// std::runtime_error carrying the library's message; the C ABI itself never throws.
+#pragma once
+#include "nbody.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace nbody {
+
+constexpr float kTimeTick = 0.008f;            // TIME_TICK, kernel.cu:63
+constexpr float kSofteningVersion3 = 1.0e-2f;  // effective eps of cal_single_acclerate_without_mass_new, :665-692
+constexpr float kSofteningVersion1 = 1.0e-3f;  // sqrt(EPSILON) of cal_single_acclerate, :808-824
+
+class System {
+public:
+    System() = default;
+    explicit System(std::int64_t numBodies, int device = 0) { initialize(numBodies, device); }
+    System(const System &) = delete;
+    System &operator=(const System &) = delete;
+    ~System() { nbody_destroy(ctx_); }
+
+    void initialize(std::int64_t numBodies, int device = 0)
+    {
+        nbody_destroy(ctx_);
+        ctx_ = nullptr;
+        check(nbody_create(&ctx_, device, numBodies), "nbody_create");
+        n_ = numBodies;
+    }
+    // One rank of a sharded run: rows [rowLo, rowLo+rowCount) against all numBodies columns.
+    void initializeShard(std::int64_t numBodies, std::int64_t rowLo, std::int64_t rowCount, std::int64_t splitLen = 0,
+                         int device = 0)
+    {
+        nbody_destroy(ctx_);
+        ctx_ = nullptr;
+        check(nbody_create_shard(&ctx_, device, numBodies, rowLo, rowCount, splitLen), "nbody_create_shard");
+        n_ = numBodies;
+    }
+
+    void setParticlesPosition(const float *xyzm) { check(nbody_set_positions(ctx_, xyzm), "nbody_set_positions"); }
+    void setParticlesVelocity(const float *xyzw) { check(nbody_set_velocities(ctx_, xyzw), "nbody_set_velocities"); }
+    void download(float *xyzm, float *xyzw) { check(nbody_download(ctx_, xyzm, xyzw), "nbody_download"); }
+
+    // The mapped-pointer analogue of cudaGraphicsResourceGetMappedPointer (kernel.cu:1226).
+    float *positionsDevice() { return nbody_positions_device(ctx_); }
+    float *velocitiesDevice() { return nbody_velocities_device(ctx_); }
+
+    // One synchronous step on the owned buffers (the reference synchronises after each kernel, :1232,1236).
+    void step(float dt = kTimeTick, float softening = kSofteningVersion3)
+    {
+        check(nbody_step(ctx_, positionsDevice(), velocitiesDevice(), nullptr, dt, softening), "nbody_step");
+    }
+    // step(positions, velocities, masses, dt, softening) on caller-owned device buffers.
+    void step(float *dPositions, float *dVelocities, const float *dMasses, float dt, float softening)
+    {
+        check(nbody_step(ctx_, dPositions, dVelocities, dMasses, dt, softening), "nbody_step");
+    }
+    void stepN(int k, float dt, float softening) { check(nbody_step_n(ctx_, k, dt, softening), "nbody_step_n"); }
+
+    struct Energy { double kinetic, potential, total; };
+    Energy energy(float softening)
+    {
+        double e[3];
+        check(nbody_energy(ctx_, positionsDevice(), velocitiesDevice(), softening, e), "nbody_energy");
+        return {e[0], e[1], e[2]};
+    }
+    std::vector<double> momentum()
+    {
+        std::vector<double> p(4);
+        check(nbody_momentum(ctx_, positionsDevice(), velocitiesDevice(), p.data()), "nbody_momentum");
+        return p;
+    }
+
+    void timing(bool on) { check(nbody_timing_enable(ctx_, on ? 1 : 0), "nbody_timing_enable"); }
+    struct Timing { double forceMs, updateMs; std::int64_t forceLaunches, updateLaunches; };
+    Timing readTiming()
+    {
+        Timing t{};
+        check(nbody_timing_read(ctx_, &t.forceMs, &t.forceLaunches, &t.updateMs, &t.updateLaunches), "nbody_timing_read");
+        return t;
+    }
+
+    std::int64_t numBodies() const { return n_; }
+    nbody_ctx *handle() { return ctx_; }
+
+private:
+    void check(int status, const char *what)
+    {
+        if (status != NBODY_OK)
+            throw std::runtime_error(std::string(what) + ": " + nbody_last_error(ctx_) + " (" +
+                                     nbody_status_string(status) + ")");
+    }
+    nbody_ctx *ctx_ = nullptr;
+    std::int64_t n_ = 0;
+};
+
+}  // namespace nbody

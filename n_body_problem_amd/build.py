@@ -49,5 +49,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(PKG_DIR, "..", "host")
+HOST_BIN = os.path.join(HOST_DIR, "nbody_run")
+
+
+def build_host(force: bool = False) -> str:
+    """The thin C++ host (host/nbody_run.cpp): plain g++ against the C ABI, no HIP headers needed."""
+    src = os.path.join(HOST_DIR, "nbody_run.cpp")
+    deps = [src, os.path.join(HOST_DIR, "nbody_io.hpp"), os.path.join(PKG_DIR, "..", "include", "nbody.hpp"),
+            os.path.join(PKG_DIR, "..", "include", "nbody.h"), LIB_PATH]
+    if not force and os.path.exists(HOST_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_BIN) for d in deps):
+        return HOST_BIN
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(PKG_DIR, "..", "include"), src, "-L" + PKG_DIR,
+           "-lnbody_amd", "-L/opt/rocm/lib", "-Wl,-rpath,$ORIGIN/../n_body_problem_amd", "-Wl,-rpath,/opt/rocm/lib",
+           "-o", HOST_BIN]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed building host/nbody_run:\n" + res.stderr[-4000:])
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_host(force=True))

@@ -1,0 +1,80 @@
+"""CPU-only: the reference's dataset formats and the raw snapshot format (N3)."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from n_body_problem_amd import datasets as ds
+from n_body_problem_amd import initial_conditions as ic
+
+REF_DATA = "/root/reference/main_project/data"
+
+
+def sample(n=37):
+    pos, vel = ic.uniform_cube(n, seed=77, random_masses=True, speed=0.3)
+    vel[:, 3] = np.linspace(0.01, 0.02, n, dtype=np.float32)   # per-particle eps travels in vel.w
+    return pos, vel
+
+
+def test_tipsy_round_trip_and_record_sizes(tmp_path):
+    pos, vel = sample(37)
+    f = str(tmp_path / "g.bin")
+    ds.write_tipsy(f, pos, vel, ndark=5, time=1.5)
+    assert os.path.getsize(f) == 32 + 5 * 36 + 32 * 44
+    p, v = ds.read_tipsy(f)
+    assert np.array_equal(p, pos) and np.array_equal(v, vel)
+    # galaxy_20K.bin: 2500 dark + 17500 star = 860032 bytes
+    assert 32 + 2500 * 36 + 17500 * 44 == 860032
+
+
+def test_text_formats_round_trip(tmp_path):
+    pos, vel = sample(20)
+    f = str(tmp_path / "a.tab")
+    ds.write_tab(f, pos, vel)
+    open(f, "a").write("\n\n")                      # trailing blank lines must not become bodies (Q8)
+    p, v = ds.read_tab(f)
+    assert np.array_equal(p, pos) and np.array_equal(v[:, :3], vel[:, :3]) and np.all(v[:, 3] == 0)
+    f = str(tmp_path / "a.dat")
+    ds.write_dat(f, pos, vel)
+    p, v = ds.read_dat(f)                            # z y x order on disk, mass forced to 1
+    assert np.array_equal(p[:, :3], pos[:, :3]) and np.all(p[:, 3] == 1) and np.array_equal(v[:, :3], vel[:, :3])
+    f = str(tmp_path / "a.snap")
+    ds.write_snap(f, pos, vel, time=7.75)
+    p, v = ds.read_snap(f)
+    assert np.array_equal(p, pos) and np.array_equal(v, vel)
+    assert np.array_equal(ds.read_any(f)[0], pos)
+    with pytest.raises(ValueError):
+        ds.read_any(str(tmp_path / "a.xyz"))
+
+
+def test_snapshot_round_trip(tmp_path):
+    pos, vel = sample(1000)
+    f = str(tmp_path / "s.nbs")
+    ds.save_snapshot(f, pos, vel, step=42, time=0.336)
+    p, v, step, time = ds.load_snapshot(f)
+    assert np.array_equal(p, pos) and np.array_equal(v, vel) and step == 42 and time == pytest.approx(0.336)
+    open(f, "r+b").truncate(100)
+    with pytest.raises(ValueError):
+        ds.load_snapshot(f)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference's data files are not on this machine")
+def test_reference_files_known_answers():
+    """F4 of SURVEY.md 8c: galaxy_20K.bin parsed with the reference's structs equals its own CSV dump
+    (unused_files/tool.cpp wrote galaxy_20k.csv from that file)."""
+    pos, vel = ds.load_reference_dataset(0, REF_DATA)
+    assert pos.shape == (20000, 4)
+    rows = list(csv.reader(open(os.path.join(REF_DATA, "galaxy_20k.csv"))))[1:]
+    assert len(rows) == 20000
+    for i in (0, 1, 2, 2499, 2500, 19999):
+        want = np.array([float(x) for x in rows[i][1:]])      # x,y,z,mass,vx,vy,vz,eps
+        got = np.array([*pos[i, :3], pos[i, 3], *vel[i, :3], vel[i, 3]], dtype=np.float64)
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-12), i   # the CSV keeps 6 significant digits
+    p, v = ds.load_reference_dataset(3, REF_DATA)              # stars.dat: "z y x vz vy vx", mass 1
+    first = [float(x) for x in open(os.path.join(REF_DATA, "stars.dat")).readline().split()]
+    assert np.allclose(p[0, :3], first[2::-1], rtol=1e-6) and np.allclose(v[0, :3], first[5:2:-1], rtol=1e-6)
+    assert p.shape[0] == 43802 and np.all(p[:, 3] == 1)      # 43837 lines, 35 records wrapped over two lines
+    p, v = ds.load_reference_dataset(5, REF_DATA)              # k17hp.snap through the .snap parser
+    assert p.shape == (10002, 4) and p[0, 3] == pytest.approx(2e-4)
+    assert ic.padded_count(20000) == 20225                     # the count the reference hard-codes at kernel.cu:1130

@@ -1,0 +1,63 @@
+"""GPU: the C++ host (host/nbody_run) drives the same C ABI as the Python mirror -- same bits -- and its
+snapshot dump/resume continues a run exactly."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(*args):
+    from n_body_problem_amd import build
+    exe = build.build_host()
+    res = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    return res.stdout
+
+
+def test_cli_matches_python_mirror_and_resumes_exactly(tmp_path):
+    import n_body_problem_amd as nb
+    from n_body_problem_amd import datasets as ds
+    pos, vel = nb.plummer(5000, seed=91)
+    start = str(tmp_path / "start.nbs")
+    ds.save_snapshot(start, pos, vel, step=0, time=0.0)
+    with nb.NBodySystem(5000) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(5, 1e-3, 1e-3)
+        want_p, want_v = s.download()
+    out = run_cli("--resume", start, "--steps", 5, "--dt", 1e-3, "--softening", 1e-3, "--energy-every", 5,
+                  "--final", tmp_path / "five.nbs")
+    assert "interactions/s" in out and "dE/E0" in out
+    p, v, step, time = ds.load_snapshot(str(tmp_path / "five.nbs"))
+    assert step == 5 and time == pytest.approx(5e-3)
+    assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
+    # 3 steps, dump, resume for 2 more: identical to 5 in one go
+    run_cli("--resume", start, "--steps", 3, "--dt", 1e-3, "--softening", 1e-3, "--dump-every", 3, "--dump-prefix",
+            tmp_path / "run")
+    run_cli("--resume", tmp_path / "run_000003.nbs", "--steps", 2, "--dt", 1e-3, "--softening", 1e-3, "--final",
+            tmp_path / "resumed.nbs")
+    p2, v2, step2, _ = ds.load_snapshot(str(tmp_path / "resumed.nbs"))
+    assert step2 == 5 and np.array_equal(p2, want_p) and np.array_equal(v2, want_v)
+
+
+def test_cli_reads_the_reference_formats(tmp_path):
+    import n_body_problem_amd as nb
+    from n_body_problem_amd import datasets as ds
+    pos, vel = nb.uniform_cube(300, seed=5, random_masses=True, speed=0.1)
+    f = str(tmp_path / "g.bin")
+    ds.write_tipsy(f, pos, vel, ndark=100)
+    run_cli("--file", f, "--steps", 2, "--final", tmp_path / "o.nbs", "--pad-reference")   # reference dt / softening
+    p, v, _, _ = ds.load_snapshot(str(tmp_path / "o.nbs"))
+    assert p.shape[0] == nb.padded_count(300)
+    with nb.NBodySystem(300) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(2, nb.TIME_TICK, nb.SOFTENING_VERSION3)
+        want_p, want_v = s.download()
+    err = np.abs(p[:300, :3] - want_p[:, :3]).max() / np.abs(want_p[:, :3]).max()
+    assert err < 1e-6 and np.array_equal(v[:300, 3], vel[:, 3])
