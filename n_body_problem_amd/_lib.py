@@ -71,6 +71,12 @@ def load() -> ctypes.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc, gfx950).  n_body_problem_amd has no CPU or PyTorch fallback.")
+        try:
+            # PyTorch-ROCm ships its own HIP runtime: let it load first so that this library binds to the same
+            # one (loading the system runtime first and torch's second leaves the process without a device)
+            import torch  # noqa: F401
+        except ImportError:  # a torch-free host (ctypes only) uses the system runtime
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
