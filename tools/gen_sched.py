@@ -35,6 +35,8 @@ OPS = {
     "a0": "v_fmac_f32_e32 {AX}, {D0}, {R}", "a1": "v_fmac_f32_e32 {AY}, {D1}, {R}", "a2": "v_fmac_f32_e32 {AZ}, {D2}, {R}",
     "nop": "s_nop 0",
     # variants
+    "f1v": "v_fma_f32 {R}, {D1}, {D1}, {R}", "f2v": "v_fma_f32 {R}, {D2}, {D2}, {R}", "m0v": "v_mul_f32_e64 {Q}, {R}, {R}",
+    "m0c": "v_mul_f32_e32 {Q}, {R}, {R}",
     "m0b": "v_mul_f32_e32 {Q}, {pm}, {R}",            # s = (m*inv) first: consumes the rsq with distinct registers
     "m1b": "v_mul_f32_e32 {R}, {R}, {R}",             # inv^2 in place
     "m2b": "v_mul_f32_e32 {R}, {R}, {Q}",
@@ -133,61 +135,65 @@ def add(pid, desc, units, sched=None, rawlines=None, rep=4):
 
 
 P4 = rows(4, 0)
-P8 = rows(4, 0) + rows(4, 1)
-add("seq4", "row after row, s_nop after rsq (hipcc's shape)", 4, sched_seq(P4))
-add("seq4alt", "row after row, rsq consumed by m*inv (distinct regs)", 4, sched_seq_altconsume(P4))
-add("b4stage", "4 rsq batched, rest stage by stage", 4, sched_batch(P4))
-add("b4chain", "4 rsq batched, rest chain by chain", 4, sched_batch(P4, chain_post=True))
-add("b4m0", "4 rsq batched, 4 x inv*inv at once, rest chain by chain", 4, sched_batch_m0_then_chain(P4))
-add("b8m0", "8 rsq batched (2 columns), 8 x inv*inv, rest chain by chain", 8, sched_batch_m0_then_chain(P8), rep=2)
-add("b8stage", "8 rsq batched, rest stage by stage", 8, sched_batch(P8), rep=2)
-add("g2m0", "pairs: 2 rsq batched, 2 x inv*inv, rest chain by chain", 4, sched_groups(P4, 2))
-P16 = [(k, u) for u in range(4) for k in range(4)]
-P16r8 = [(k, u) for u in range(2) for k in range(8)]
-add("b16stage", "16 rsq batched (4 rows x 4 columns), rest stage by stage", 16, sched_batch(P16), rep=1)
-add("b16chain", "16 rsq batched, rest chain by chain", 16, sched_batch(P16, chain_post=True), rep=1)
-add("b16r8", "16 rsq batched (8 rows x 2 columns), rest chain by chain", 16, sched_batch(P16r8, chain_post=True), rep=1)
-# isolated probes
-add("r1c_f7", "rsq, s_nop, dependent mul (consume), 7 fmac  [model 8+2+14.4=24.4]", 1,
-    rawlines=["v_rsq_f32_e32 v40, v40", "s_nop 0", "v_mul_f32_e32 v41, v40, v3"] + FM[:7], rep=8)
-add("r1c_f15", "rsq, s_nop, consume, 15 fmac  [model 40.8]", 1,
-    rawlines=["v_rsq_f32_e32 v40, v40", "s_nop 0", "v_mul_f32_e32 v41, v40, v3"] + FM[:7] + FM, rep=8)
-add("r1c_f31", "rsq, s_nop, consume, 31 fmac  [model 73.6]", 1,
-    rawlines=["v_rsq_f32_e32 v40, v40", "s_nop 0", "v_mul_f32_e32 v41, v40, v3"] + FM[:7] + FM * 3, rep=8)
-add("r1_f31_c", "rsq, 31 fmac, then consume", 1,
-    rawlines=["v_rsq_f32_e32 v40, v40"] + FM[:7] + FM * 3 + ["v_mul_f32_e32 v41, v40, v3"], rep=8)
-add("r1c_f63", "rsq, s_nop, consume, 63 fmac  [model 139]", 1,
-    rawlines=["v_rsq_f32_e32 v40, v40", "s_nop 0", "v_mul_f32_e32 v41, v40, v3"] + FM[:7] + FM * 7, rep=4)
-add("r1_f63", "rsq, 63 fmac, never consumed", 1, rawlines=["v_rsq_f32_e32 v40, v40"] + FM[:7] + FM * 7, rep=4)
-add("r1_f127", "rsq, 127 fmac, never consumed", 1, rawlines=["v_rsq_f32_e32 v40, v40"] + FM[:7] + FM * 15, rep=2)
-add("r4c_f28", "4 rsq, s_nop, 4 consumes, 28 fmac", 1,
-    rawlines=["v_rsq_f32_e32 v40, v40", "v_rsq_f32_e32 v41, v41", "v_rsq_f32_e32 v42, v42", "v_rsq_f32_e32 v43, v43",
-              "v_mul_f32_e32 v44, v40, v3", "v_mul_f32_e32 v45, v41, v3", "v_mul_f32_e32 v46, v42, v3", "v_mul_f32_e32 v47, v43, v3"]
-    + FM[:4] + FM * 3, rep=8)
-add("f32only", "32 fmac only  [model 65.6]", 1, rawlines=FM * 4, rep=8)
-add("sq_fwd", "8 x (sub d; fma r,d,d,eps): square of a just-written register", 8,
-    rawlines=sum([[f"v_sub_f32_e32 v{45+8*i}, v0, v{13+4*(i%4)}", f"v_fma_f32 v{40+8*i}, v{45+8*i}, v{45+8*i}, v8"] for i in range(8)], []), rep=4)
-add("sq_old", "8 x fma r,d,d,eps with d written long ago", 8,
-    rawlines=[f"v_fma_f32 v{40+8*i}, v{45+8*i}, v{45+8*i}, v8" for i in range(8)], rep=8)
-add("exp1_f7", "v_exp_f32 + 7 fmac", 1, rawlines=["v_exp_f32_e32 v40, v40"] + FM[:7], rep=8)
-add("rcp1_f7", "v_rcp_f32 + 7 fmac", 1, rawlines=["v_rcp_f32_e32 v40, v40"] + FM[:7], rep=8)
-add("sqrt1_f7", "v_sqrt_f32 + 7 fmac", 1, rawlines=["v_sqrt_f32_e32 v40, v40"] + FM[:7], rep=8)
-add("cvt1_f7", "v_cvt_f32_i32 + 7 fmac", 1, rawlines=["v_cvt_f32_i32_e32 v40, v40"] + FM[:7], rep=8)
-add("f64_f7", "v_fma_f64 + 7 fmac", 1, rawlines=["v_fma_f64 v[40:41], v[42:43], v[44:45], v[40:41]"] + FM[:7], rep=8)
-add("mov1_f7", "v_mov_b32 + 7 fmac", 1, rawlines=["v_mov_b32_e32 v40, v41"] + FM[:7], rep=8)
-add("rsq16_f7", "v_rsq_f16 + 7 fmac", 1, rawlines=["v_rsq_f16_e32 v40, v40"] + FM[:7], rep=8)
+FMX = [f"v_fmac_f32_e32 v{180 + (i % 16)}, v0, v1" for i in range(64)]
+import os as _os
+MODE = _os.environ.get("SCHED_MODE", "scan")
+
+def sym_step(pp, R=1, lds=True):
+    """one step of the symmetric (pair-once) scheme: column body of lane (l+s) from LDS, R row bodies per lane,
+    column accumulators rotate by one lane per step (v_add_f32_dpp wave_ror:1, ping-pong registers)."""
+    ca = [f"v{60+3*pp+i}" for i in range(3)]
+    cb = [f"v{60+3*(1-pp)+i}" for i in range(3)]
+    L = []
+    if lds:
+        L += ["ds_read_b128 v[0:3], v10", "s_waitcnt lgkmcnt(0)"]
+    for k in range(R):
+        X, Y, Z, M = f"v{13+4*k}", f"v{14+4*k}", f"v{15+4*k}", f"v{16+4*k}"
+        AX, AY, AZ = f"v{100+3*k}", f"v{101+3*k}", f"v{102+3*k}"
+        D0, D1, D2, RR, Q, SC = "v45", "v46", "v47", "v40", "v41", "v42"
+        L += [f"v_sub_f32_e32 {D0}, v0, {X}", f"v_sub_f32_e32 {D1}, v1, {Y}", f"v_sub_f32_e32 {D2}, v2, {Z}",
+              f"v_fma_f32 {RR}, {D0}, {D0}, v176", f"v_fmac_f32_e32 {RR}, {D1}, {D1}", f"v_fmac_f32_e32 {RR}, {D2}, {D2}",
+              f"v_rsq_f32_e32 {RR}, {RR}", "s_nop 0",
+              f"v_mul_f32_e32 {Q}, {RR}, {RR}", f"v_mul_f32_e32 {RR}, {RR}, {Q}",
+              f"v_mul_f32_e32 {SC}, {M}, {RR}", f"v_mul_f32_e32 {RR}, v3, {RR}",
+              f"v_fmac_f32_e32 {AX}, {D0}, {RR}", f"v_fmac_f32_e32 {AY}, {D1}, {RR}", f"v_fmac_f32_e32 {AZ}, {D2}, {RR}"]
+        if k == 0:
+            L += [f"v_mul_f32_e32 {D0}, {D0}, {SC}", f"v_mul_f32_e32 {D1}, {D1}, {SC}", f"v_mul_f32_e32 {D2}, {D2}, {SC}",
+                  f"v_add_f32_dpp {cb[0]}, {ca[0]}, {D0} wave_ror:1 row_mask:0xf bank_mask:0xf",
+                  f"v_add_f32_dpp {cb[1]}, {ca[1]}, {D1} wave_ror:1 row_mask:0xf bank_mask:0xf",
+                  f"v_add_f32_dpp {cb[2]}, {ca[2]}, {D2} wave_ror:1 row_mask:0xf bank_mask:0xf"]
+        else:
+            L += [f"v_fmac_f32_e32 {cb[0]}, {D0}, {SC}", f"v_fmac_f32_e32 {cb[1]}, {D1}, {SC}", f"v_fmac_f32_e32 {cb[2]}, {D2}, {SC}"]
+    return L
 
 
+add("seq4", "reference point: one-sided, row after row (per ORDERED interaction)", 4, sched_seq(P4))
+for R in (1, 2, 4):
+    add(f"sym{R}", f"symmetric step, {R} row(s) per lane, column from LDS (per PAIR = 2 ordered interactions)", 2 * R,
+        rawlines=sym_step(0, R) + sym_step(1, R), rep=4)
+add("sym1_nolds", "symmetric step, 1 row, no LDS read (per pair)", 2, rawlines=sym_step(0, 1, False) + sym_step(1, 1, False), rep=4)
+add("dpp8", "8 x v_add_f32_dpp wave_ror:1", 8,
+    rawlines=[f"v_add_f32_dpp v{60+i}, v{70+i}, v0 wave_ror:1 row_mask:0xf bank_mask:0xf" for i in range(8)], rep=8)
+add("movdpp8", "8 x v_mov_b32_dpp wave_ror:1", 8,
+    rawlines=[f"v_mov_b32_dpp v{60+i}, v{70+i} wave_ror:1 row_mask:0xf bank_mask:0xf" for i in range(8)], rep=8)
+add("dpprow8", "8 x v_add_f32_dpp row_ror:1 (within 16 lanes)", 8,
+    rawlines=[f"v_add_f32_dpp v{60+i}, v{70+i}, v0 row_ror:1 row_mask:0xf bank_mask:0xf" for i in range(8)], rep=8)
 TEMPLATE = r'''// GENERATED by tools/gen_sched.py -- do not edit.  Steady-state SIMD cycles of instruction schedules (gfx950).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 #define CLOB %(clob)s
 #define INIT_REGS asm volatile(%(init)s ::: CLOB)
+#ifdef DENORM_FLUSH
+#define MODE_SETUP asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 0" ::: "memory")
+#else
+#define MODE_SETUP
+#endif
 #define DEF_KERNEL(ID, BODY)                                                                                       \
     __global__ __launch_bounds__(256) void rate_##ID(unsigned long long *out, unsigned ticks)                      \
     {                                                                                                              \
         INIT_REGS;                                                                                                 \
+        MODE_SETUP;                                                                                                \
         const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                            \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                \
         unsigned long long bodies = 0;                                                                             \
