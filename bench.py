@@ -58,6 +58,41 @@ def cpu_baseline(pos, softening, target_seconds):
                       f"oracle/nbody_oracle.c reference-order fp32 (extrapolates linearly in rows)"}
 
 
+def pair_once_leg(nb, n, pos, vel, args):
+    """The experimental pair-once kernel on the same state, reported BESIDE the headline, never as
+    it: N^2/t for comparison, and the roofline fraction from the pair evaluations it actually executes."""
+    import torch
+    try:
+        s = nb.NBodySystem(n)
+        s.set_force_mode("symmetric")
+    except nb.NBodyError as e:
+        return {"skipped": str(e)}
+    s.setParticlesPosition(pos)
+    s.setParticlesVelocity(vel)
+    s.timing(True)
+    s.step(args.dt, args.softening)
+    s.read_timing()
+    torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.step(args.dt, args.softening, sync=False)
+    s.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = s.read_timing()
+    L = s.split_len
+    S = -(-n // L)
+    executed = S * (S + 1) / 2 * L * L * steps
+    s.close()
+    force_s = max(tm["force_ms"] / 1e3, 1e-12)
+    return {"value": float(n) * n * steps / dt, "unit": "interactions/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "kernel": "nbody::force_sym_kernel", "executed_pair_evaluations_per_s": executed / force_s,
+            "roofline_frac_executed": FLOP_PER_INTERACTION * executed / force_s / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+            "note": "each unordered pair once, applied to both bodies; single GPU only; agrees with the headline kernel "
+                    "to rounding (tests/test_parity_gpu.py), bit-reproducible; NOT the headline value"}
+
+
 def committed_traffic(n):
     """HBM bytes per step from a committed PMC summary (profiles/*pmc*.json) for this body count, if any."""
     best = None
@@ -81,8 +116,11 @@ def main():
     ap.add_argument("--softening", type=float, default=1e-3)
     ap.add_argument("--exchange", default=os.environ.get("NBODY_EXCHANGE", "allgather"), choices=["allgather", "ring"])
     ap.add_argument("--rows-per-lane", type=int, default=0)
+    ap.add_argument("--force-mode", default="one_sided", choices=["one_sided", "symmetric"],
+                    help="symmetric = the experimental pair-once kernel (1 GPU only); roofline from EXECUTED pair evaluations")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pair-once", action="store_true", help="skip the extra leg that times the experimental pair-once kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the product path); gloo only to rehearse the multi-rank flow on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -118,6 +156,10 @@ def main():
         system = ShardedNBodySystem(n, device=local_rank, exchange=args.exchange)
         kernels = system.kernels
     kernels.set_rows_per_lane(args.rows_per_lane)
+    if args.force_mode != "one_sided":
+        if world != 1:
+            raise SystemExit("--force-mode symmetric is single-GPU")
+        kernels.set_force_mode(args.force_mode)
     system.setParticlesPosition(pos)
     system.setParticlesVelocity(vel)
     info = kernels.device_info()
@@ -152,9 +194,15 @@ def main():
         rows_here = n / world
         force_s = tm["force_ms"] / 1e3
         launches = max(tm["force_launches"], 1)
-        flop_per_launch = FLOP_PER_INTERACTION * rows_here * n * args.steps / launches
-        achieved = FLOP_PER_INTERACTION * rows_here * n * args.steps / max(force_s, 1e-12) / 1e12
-        traffic = committed_traffic(n) if world == 1 else None
+        # executed pair evaluations: N^2 ordered ones, or (S(S+1)/2) x split_len^2 unordered ones in the pair-once mode
+        executed = rows_here * n * args.steps
+        if args.force_mode == "symmetric":
+            L = kernels.split_len
+            S = -(-n // L)
+            executed = S * (S + 1) / 2 * L * L * args.steps
+        flop_per_launch = FLOP_PER_INTERACTION * executed / launches
+        achieved = FLOP_PER_INTERACTION * executed / max(force_s, 1e-12) / 1e12
+        traffic = committed_traffic(n) if world == 1 and args.force_mode == "one_sided" else None
         out = {
             "metric": "body-body interactions/sec",
             "value": interactions / elapsed,
@@ -173,12 +221,15 @@ def main():
                        "n_bodies": n, "parallelism": f"rows sharded x{world}" if world > 1 else "1 GPU",
                        "exchange": args.exchange if world > 1 else None,
                        "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
-                       "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3]},
+                       "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3],
+                       "force_mode": args.force_mode},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "nbody::force_kernel", "flop_per_launch": flop_per_launch,
+                         "kernel": "nbody::force_kernel" if args.force_mode == "one_sided" else "nbody::force_sym_kernel",
+                         "executed_pair_evaluations_per_s": executed / max(force_s, 1e-12),
+                         "flop_per_launch": flop_per_launch,
                          "avg_launch_ms": tm["force_ms"] / launches, "launches": tm["force_launches"],
                          "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used; "
                                  "20 flop per ordered interaction; rank 0's kernels"},
@@ -186,6 +237,8 @@ def main():
             "update_ms_per_step": tm["update_ms"] / args.steps,
             "device": info,
         }
+        if world == 1 and args.force_mode == "one_sided" and not args.no_pair_once:
+            out["pair_once"] = pair_once_leg(nb, n, pos, vel, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, args.softening, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

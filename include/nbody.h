@@ -133,6 +133,14 @@ int nbody_timing_enable(nbody_ctx *ctx, int on);
 int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches, double *update_ms,
                       int64_t *update_launches);
 
+/* Force algorithm.  NBODY_FORCE_ONE_SIDED (default): every ordered interaction is evaluated, rows are independent
+ * (the shape of simple_update_all, kernel.cu:828-884; shards over GPUs).  NBODY_FORCE_SYMMETRIC (experimental): each
+ * unordered pair once, applied to both bodies -- the idea of cal_acc_advanced, kernel.cu:703-774, without its float
+ * atomics; single context only (all rows), 1024 <= split_len <= 8192, whole-range nbody_forces/nbody_step calls;
+ * results agree with the default to rounding (not bit for bit) and are themselves bit-reproducible. */
+enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
+int nbody_set_force_mode(nbody_ctx *ctx, int mode);
+
 /* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default). */
 int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
 

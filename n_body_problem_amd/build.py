@@ -13,7 +13,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnbody_amd.so")
-SOURCES = ["nbody_kernels.hip", "nbody_capi.hip"]
+SOURCES = ["nbody_kernels.hip", "nbody_symmetric.hip", "nbody_capi.hip"]
 HEADERS = [os.path.join(CSRC, "nbody_kernels.h"), os.path.join(PKG_DIR, "..", "include", "nbody.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ffp-contract=off",
@@ -35,17 +35,36 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+#: per-source extra flags.  The pair-once kernel is built without SLP vectorisation: v_pk_*_f32 buys nothing on gfx950
+#: (4 cycles for two lanes' worth) and the packing moves break its row-after-row chains.
+EXTRA_FLAGS = {"nbody_symmetric.hip": ["-fno-slp-vectorize"]}
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the shared library if missing or older than its sources; returns its path."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    objdir = os.path.join(PKG_DIR, "..", "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc(), *compile_flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or res.returncode != 0:
+            print(" ".join(cmd))
+            print(res.stdout + res.stderr)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed compiling {src}:\n" + res.stderr[-4000:])
+        objs.append(obj)
+    cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB_PATH]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
         print(res.stdout + res.stderr)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed building libnbody_amd.so:\n" + res.stderr[-4000:])
+        raise RuntimeError("hipcc failed linking libnbody_amd.so:\n" + res.stderr[-4000:])
     return LIB_PATH
 
 

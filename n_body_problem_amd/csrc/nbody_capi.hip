@@ -17,6 +17,9 @@ struct nbody_ctx {
     int64_t n_total = 0, row_lo = 0, row_count = 0, split_len = 0;
     int n_splits = 0;
     int rows_per_lane = 0;  // 0 = pick per launch
+    int force_mode = NBODY_FORCE_ONE_SIDED;
+    int2 *sym_tiles = nullptr;  // pair-once mode: the (I <= J) split pairs, one workgroup each
+    int sym_n_tiles = 0;
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream or the caller's)
@@ -180,6 +183,7 @@ int nbody_destroy(nbody_ctx *c)
     if (c->pos) (void)hipFree(c->pos);
     if (c->vel) (void)hipFree(c->vel);
     if (c->reduce_dev) (void)hipFree(c->reduce_dev);
+    if (c->sym_tiles) (void)hipFree(c->sym_tiles);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return NBODY_OK;
@@ -339,6 +343,32 @@ int nbody_timing_read(nbody_ctx *c, double *force_ms, int64_t *force_launches, d
 
 // ---- the step -------------------------------------------------------------------------------
 
+int nbody_set_force_mode(nbody_ctx *c, int mode)
+{
+    if (!c || (mode != NBODY_FORCE_ONE_SIDED && mode != NBODY_FORCE_SYMMETRIC))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_force_mode: unknown mode");
+    if (mode == NBODY_FORCE_SYMMETRIC) {
+        if (c->row_lo != 0 || c->row_count != c->n_total)
+            return fail(c, NBODY_ERR_INVALID, "nbody_set_force_mode: the pair-once mode needs all rows in one context");
+        if (c->split_len < 1024 || c->split_len > 8192)
+            return fail(c, NBODY_ERR_INVALID,
+                        "nbody_set_force_mode: the pair-once mode needs 1024 <= split_len <= 8192 (n_total >= 16384, "
+                        "or an explicit split_len at nbody_create_shard)");
+        if (!c->sym_tiles) {
+            std::vector<int2> tiles;
+            for (int i = 0; i < c->n_splits; ++i)
+                for (int j = i; j < c->n_splits; ++j)
+                    tiles.push_back(make_int2(i, j));
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipMalloc((void **)&c->sym_tiles, sizeof(int2) * tiles.size()));
+            HIP_TRY(c, hipMemcpy(c->sym_tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice));
+            c->sym_n_tiles = (int)tiles.size();
+        }
+    }
+    c->force_mode = mode;
+    return NBODY_OK;
+}
+
 int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
 {
     if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == 8))
@@ -375,6 +405,25 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return fail(c, NBODY_ERR_INVALID, std::string(who) + ": column range must be split-aligned and inside [0,n_total]");
     if (c->row_count == 0 || c->n_total == 0)
         return NBODY_OK;
+    if (c->force_mode == NBODY_FORCE_SYMMETRIC) {
+        if (complement || col_lo != 0 || col_lo + col_count != c->n_total)
+            return fail(c, NBODY_ERR_INVALID, std::string(who) + ": the pair-once mode computes all columns in one call");
+        SymArgs sa;
+        sa.pos = reinterpret_cast<const float4 *>(d_pos);
+        sa.partials = c->partials;
+        sa.tiles = c->sym_tiles;
+        sa.n_tiles = c->sym_n_tiles;
+        sa.n_total = (int)c->n_total;
+        sa.split_len = (int)c->split_len;
+        sa.eps2 = softening * softening;
+        HIP_TRY(c, hipSetDevice(c->device));
+        {
+            TimedLaunch t(c, &c->ev_force);
+            HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
+        }
+        std::fill(c->split_done.begin(), c->split_done.end(), 1);
+        return NBODY_OK;
+    }
     const int first = (int)(col_lo / c->split_len);
     const int count = (int)((col_count + c->split_len - 1) / c->split_len);
     ForceArgs a;

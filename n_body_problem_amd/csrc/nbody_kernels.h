@@ -22,6 +22,19 @@ struct ForceArgs {
     float eps2;          // softening length squared
 };
 
+// EXPERIMENTAL pair-once kernel (nbody_symmetric.hip): one workgroup per pair of splits (I <= J).
+struct SymArgs {
+    const float4 *pos;   // all n_total bodies
+    float4 *partials;    // [n_splits][n_total]
+    const int2 *tiles;   // n_tiles pairs (I, J), I <= J
+    int n_tiles;
+    int n_total;
+    int split_len;       // 1024 <= split_len <= 8192, multiple of 256
+    float eps2;
+};
+hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);
+size_t symmetric_lds_bytes(int split_len);
+
 // Partial accelerations of rows [row_lo,row_lo+row_count) from splits [split_first, split_first+split_count).
 // rows_per_lane in {1,2,4,8}.  eps2 == 0 selects the zero-distance-guarded variant.
 hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stream);

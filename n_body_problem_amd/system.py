@@ -191,6 +191,11 @@ class NBodySystem:
         return {"force_ms": f_ms.value, "force_launches": f_n.value, "update_ms": u_ms.value,
                 "update_launches": u_n.value}
 
+    def set_force_mode(self, mode: str) -> None:
+        """``"one_sided"`` (default) or ``"symmetric"`` (experimental pair-once kernel, single context only)."""
+        code = {"one_sided": 0, "symmetric": 1}[mode]
+        check(self._lib.nbody_set_force_mode(self._ctx, code), self._ctx)
+
     def set_rows_per_lane(self, rpl: int) -> None:
         check(self._lib.nbody_set_rows_per_lane(self._ctx, int(rpl)), self._ctx)
 

@@ -316,3 +316,48 @@ def test_full_size_n1048576_properties(nb, oracle_mod):
     net = (m[:, None] * acc).sum(0)
     scale = (m[:, None] * np.abs(acc)).sum(0)
     assert np.all(np.abs(net) < 1e-5 * scale)
+
+
+# ---- N1: the experimental pair-once (symmetric) force kernel ---------------------------------------------
+
+def sym_run(nb, pos, vel, dt, eps, steps, mode, split_len=0):
+    with nb.NBodySystem(pos.shape[0], split_len=split_len) as s:
+        s.set_force_mode(mode)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(steps, dt, eps)
+        return s.download()
+
+
+@pytest.mark.parametrize("n,split_len", [(16384, 0), (20000, 0), (5000, 1024), (65536, 0)])
+def test_symmetric_mode_matches_oracle_and_one_sided(nb, oracle_mod, n, split_len):
+    pos, vel = nb.uniform_cube(n, seed=200 + n, random_masses=True, speed=0.2) if n < 30000 else nb.plummer(n, seed=n)
+    zero = np.zeros_like(vel)
+    a_sym = sym_run(nb, pos, zero, 1.0, 1e-3, 1, "symmetric", split_len)[1][:, :3]     # dt = 1, v0 = 0: v = a
+    a_one = sym_run(nb, pos, zero, 1.0, 1e-3, 1, "one_sided", split_len)[1][:, :3]
+    rows = slice(0, n) if n <= 20000 else slice(n // 2 - 1024, n // 2 + 1024)
+    a64 = oracle_mod.accel_f64(pos, i0=rows.start, i1=rows.stop, eps=1e-3)
+    assert np.linalg.norm(a_sym[rows] - a64) / np.linalg.norm(a64) < TOL
+    assert np.linalg.norm(a_sym - a_one) / np.linalg.norm(a_one) < 1e-6
+    # Newton's third law holds to rounding for every pair, so the net force is tiny
+    m = pos[:, 3:4].astype(np.float64)
+    assert np.all(np.abs((m * a_sym).sum(0)) < 1e-6 * (m * np.abs(a_sym)).sum(0))
+    p1, v1 = sym_run(nb, pos, vel, 1e-3, 1e-3, 3, "symmetric", split_len)
+    p2, v2 = sym_run(nb, pos, vel, 1e-3, 1e-3, 3, "symmetric", split_len)
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2)                           # bit-reproducible
+    pr, vr = sym_run(nb, pos, vel, 1e-3, 1e-3, 3, "one_sided", split_len)
+    assert rel_state_error(p1, pr) < 1e-6 and rel_state_error(v1, vr) < 1e-6
+
+
+def test_symmetric_mode_zero_softening_and_limits(nb):
+    pos, vel = nb.uniform_cube(16384, seed=9, random_masses=True)
+    pos[5] = pos[6]                                   # two coincident bodies
+    a = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "symmetric")[1][:, :3]
+    b = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "one_sided")[1][:, :3]
+    assert np.all(np.isfinite(a)) and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
+    with nb.NBodySystem(4096) as s:                   # split_len = 256 < 1024
+        with pytest.raises(nb.NBodyError):
+            s.set_force_mode("symmetric")
+    with nb.NBodySystem(32768, row_lo=0, row_count=16384) as s:
+        with pytest.raises(nb.NBodyError):
+            s.set_force_mode("symmetric")
