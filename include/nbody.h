@@ -141,7 +141,8 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 
-/* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default). */
+/* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default = 4, the kernel
+ * with the hand-allocated inner loop; -4 = four rows with the compiler-allocated loop).  Never changes a result bit. */
 int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
 
 /* Device facts for the roofline: out = {compute units, max clock MHz, wavefront size, LDS bytes per CU}. */

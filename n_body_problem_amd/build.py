@@ -35,9 +35,9 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-#: per-source extra flags.  The pair-once kernel is built without SLP vectorisation: v_pk_*_f32 buys nothing on gfx950
-#: (4 cycles for two lanes' worth) and the packing moves break its row-after-row chains.
-EXTRA_FLAGS = {"nbody_symmetric.hip": ["-fno-slp-vectorize"]}
+#: per-source extra flags.  The force kernels are built without SLP vectorisation: v_pk_*_f32 buys nothing on gfx950
+#: (4 cycles for two lanes' worth) and the packing moves break their hand-ordered instruction phases.
+EXTRA_FLAGS = {"nbody_symmetric.hip": ["-fno-slp-vectorize"], "nbody_kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:

@@ -371,21 +371,21 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
 
 int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
 {
-    if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == 8))
-        return fail(c, NBODY_ERR_INVALID, "nbody_set_rows_per_lane: expected 0, 1, 2, 4 or 8");
+    if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == -4 || rpl == 8))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_rows_per_lane: expected 0, 1, 2, 4, 8 or -4");
     c->rows_per_lane = rpl;
     return NBODY_OK;
 }
 
-// Largest register blocking that still leaves every CU several workgroups (8 rows per lane measured
-// fastest at N = 2^20: one broadcast LDS read feeds 8 interactions).  Speed only: each row's sum is the
-// same FMA chain whatever the blocking.
+// Largest register blocking that still leaves every CU several workgroups; 4 rows per lane (4 v_rsq_f32 per
+// batch, 8 waves per SIMD) measured fastest.  Speed only: each row's sum is the same FMA chain whatever the
+// blocking.
 static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
 {
     if (c->rows_per_lane)
         return c->rows_per_lane;
     const int64_t want = 4LL * c->cu_count;
-    for (int rpl : {8, 4, 2}) {
+    for (int rpl : {4, 2}) {
         int64_t blocks = (c->row_count + (int64_t)kTile * rpl - 1) / ((int64_t)kTile * rpl) * split_count;
         if (blocks >= want)
             return rpl;

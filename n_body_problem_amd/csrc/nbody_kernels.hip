@@ -6,35 +6,27 @@
 //   simple_update_all         :828-884  the GPU-Gems shape: 1 body per thread, 256-body shared tile
 // Written from scratch for CDNA4: 64-lane wavefronts, column tiles staged in LDS and read back as
 // wave-uniform (broadcast) ds_read_b128, several rows register-blocked per lane so each LDS read
-// feeds rows_per_lane interactions, v_rsq_f32 for the inverse square root, no atomics (the
-// reference's shared/global float atomics, kernel.cu:758-773, are what it names as its bottleneck).
+// feeds rows_per_lane interactions, v_rsq_f32 for the inverse square root, issued in batches with an
+// idle gap behind them (see force_kernel), no atomics (the reference's shared/global float atomics,
+// kernel.cu:758-773, are what it names as its bottleneck).
 // The kernel is VALU-bound; HBM traffic is the O(N) state plus the partials.
 #include "nbody_kernels.h"
 
 namespace nbody {
 
-// One body-body interaction: 3 sub, 3 fma (r^2+eps^2), 1 rsq, 3 mul, 3 fma = 13 VALU instructions,
-// counted as 20 flop.  The softening is folded into the r^2 FMA chain
+// One body-body interaction: 3 sub, 3 fma (r^2+eps^2), 1 rsq, 3 mul, 3 fma = 12 fp32 VALU instructions + 1
+// transcendental, counted as 20 flop.  The softening is folded into the r^2 FMA chain
 // (kernel.cu:679 adds EPSILON separately, in double).
-template <bool GUARD>
-__device__ __forceinline__ void interact(float xi, float yi, float zi, const float4 pj, float eps2, float &ax,
-                                         float &ay, float &az)
-{
-    const float dx = pj.x - xi;
-    const float dy = pj.y - yi;
-    const float dz = pj.z - zi;
-    float r2 = __builtin_fmaf(dx, dx, eps2);
-    r2 = __builtin_fmaf(dy, dy, r2);
-    r2 = __builtin_fmaf(dz, dz, r2);
-    if (GUARD)  // eps == 0: a pair at zero distance (the self pair) must contribute 0, not NaN
-        r2 = __builtin_fmaxf(r2, 1.0e-24f);
-    const float inv = __builtin_amdgcn_rsqf(r2);
-    const float inv2 = inv * inv;
-    const float s = (pj.w * inv) * inv2;  // m_j / (r^2+eps^2)^(3/2)
-    ax = __builtin_fmaf(dx, s, ax);
-    ay = __builtin_fmaf(dy, s, ay);
-    az = __builtin_fmaf(dz, s, az);
-}
+//
+// Scheduling (measured on gfx950, tools/ubench_spec.hip and tools/gen_sched2.py): the
+// fp32 instructions a wave issues right after its own v_rsq_f32 run at about half rate for a few tens of
+// cycles, whatever they depend on.  So the RPL interactions of one column are issued in three phases --
+// [RPL x (sub, sub, sub, fma, fma, fma)] [RPL x v_rsq_f32] [idle kGap wait states] [RPL x (mul, mul, mul, fma,
+// fma, fma)] -- and the wave idles through the slow window while the SIMD's other waves issue at full rate:
+// 33.7 SIMD cycles per interaction instead of the 40.2 of the natural row-after-row order (floor: 12 x 2.05 + 8).
+template <int RPL> __device__ __forceinline__ void idle_gap() { asm volatile("s_nop 15\n\ts_nop 11"); }  // 28 wait states
+template <> __device__ __forceinline__ void idle_gap<2>() { asm volatile("s_nop 15"); }                      // 16
+template <> __device__ __forceinline__ void idle_gap<1>() { asm volatile("s_nop 15\n\ts_nop 15"); }         // 32
 
 // grid.x = row tiles of kTile*RPL rows, grid.y = splits of this launch.  Each lane owns RPL rows
 // (row = tile_base + k*kTile + lane-in-block, so row loads/stores are coalesced float4) and walks the
@@ -66,6 +58,8 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
         zi[k] = p.z;
         ax[k] = ay[k] = az[k] = 0.f;
     }
+    float eps2;  // kept in a VGPR: an SGPR source costs an fp32 instruction two extra cycles on gfx950
+    asm volatile("v_mov_b32 %0, %1" : "=v"(eps2) : "s"(a.eps2));
 
     // an out-of-range column is staged as a zero-mass body at the origin: it adds exactly 0
     float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -83,12 +77,41 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
         }
 
         const float4 *cur = tile[t & 1];
-#pragma unroll 8
+        float4 pj = cur[0];  // wave-uniform address: broadcast ds_read_b128
+#pragma unroll 4
         for (int jj = 0; jj < kTile; ++jj) {
-            const float4 pj = cur[jj];  // wave-uniform address: broadcast ds_read_b128
+            float dx[RPL], dy[RPL], dz[RPL], w[RPL];
 #pragma unroll
-            for (int k = 0; k < RPL; ++k)
-                interact<GUARD>(xi[k], yi[k], zi[k], pj, a.eps2, ax[k], ay[k], az[k]);
+            for (int k = 0; k < RPL; ++k) {  // phase 1: separations and r^2 + eps^2, one chain per row
+                dx[k] = pj.x - xi[k];
+                dy[k] = pj.y - yi[k];
+                dz[k] = pj.z - zi[k];
+                float r2 = __builtin_fmaf(dx[k], dx[k], eps2);
+                r2 = __builtin_fmaf(dy[k], dy[k], r2);
+                r2 = __builtin_fmaf(dz[k], dz[k], r2);
+                if (GUARD)  // eps == 0: a pair at zero distance (the self pair) must contribute 0, not NaN
+                    r2 = __builtin_fmaxf(r2, 1.0e-24f);
+                w[k] = r2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < RPL; ++k)  // phase 2: the transcendentals, back to back
+                w[k] = __builtin_amdgcn_rsqf(w[k]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 pn = cur[(jj + 1) & (kTile - 1)];  // the next column's LDS read travels during the gap
+            __builtin_amdgcn_sched_barrier(0);
+            idle_gap<RPL>();  // phase 3: sit out the slow window
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {  // phase 4: m_j / (r^2+eps^2)^(3/2) and the accumulation
+                const float inv = w[k];
+                const float s = (pj.w * inv) * (inv * inv);
+                ax[k] = __builtin_fmaf(dx[k], s, ax[k]);
+                ay[k] = __builtin_fmaf(dy[k], s, ay[k]);
+                az[k] = __builtin_fmaf(dz[k], s, az[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pj = pn;
         }
 
         if (t + 1 < ntiles)
@@ -105,6 +128,134 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     }
 }
 
+// ---- the 4-rows-per-lane kernel with a hand-allocated inner loop ------------------------------------------------
+// Same arithmetic, same phases and the same per-row operation order as force_kernel<4, GUARD> (the results are
+// bit-identical; tests/test_parity_gpu.py checks it), but the 256-column tile loop is one asm block with fixed VGPRs,
+// because hipcc's register allocation is blind to the gfx950 VGPR banks: an fp32 VOP2/VOP3 instruction whose src0 and
+// src1 sit in the same bank (register index mod 4) costs two extra cycles, and the compiled loop has four to five
+// such instructions per interaction.  Allocation (bank = index mod 4):
+//   v0-3 / v4-7   column body {x,y,z,m} (banks 0,1,2,3), double-buffered: the next ds_read_b128 travels in the gap
+//   v8            eps^2 (only ever src2)            v35  1e-24 (GUARD only)          v52  LDS byte address
+//   row k=0..3    x,y,z = v(9+4k), v(10+4k), v(11+4k) (banks 1,2,3)   ax = v(12+4k)   ay,az = v(25+2k), v(26+2k)
+//   temps k       r2/inv/s = v(36+4k) (bank 0)   dx,dy,dz = v(37+4k)..v(39+4k) (banks 1,2,3)   inv^2 = v33/v34
+#define NB_PRE(PX, PY, PZ, X, Y, Z, R, D0, D1, D2, GRD)                                                          \
+    "v_sub_f32_e32 " D0 ", " PX ", " X "\n\tv_sub_f32_e32 " D1 ", " PY ", " Y "\n\tv_sub_f32_e32 " D2 ", " PZ ", " Z "\n\t" \
+    "v_fma_f32 " R ", " D0 ", " D0 ", v8\n\tv_fmac_f32_e32 " R ", " D1 ", " D1 "\n\tv_fmac_f32_e32 " R ", " D2 ", " D2 "\n\t" GRD(R)
+#define NB_NOGUARD(R) ""
+#define NB_GUARD(R) "v_max_f32_e32 " R ", v35, " R "\n\t"
+#define NB_POST(PM, AX, AY, AZ, R, D0, D1, D2, Q)                                                                \
+    "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " R ", " PM ", " R "\n\tv_mul_f32_e32 " R ", " R ", " Q "\n\t"     \
+    "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t"
+// one column: wait for its LDS read, phase 1 for the four rows, the four rsq, issue the NEXT read, idle, phase 4
+#define NB_COLUMN(PX, PY, PZ, PM, NEXT, GRD)                                                                     \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    NB_PRE(PX, PY, PZ, "v9", "v10", "v11", "v36", "v37", "v38", "v39", GRD)                                      \
+    NB_PRE(PX, PY, PZ, "v13", "v14", "v15", "v40", "v41", "v42", "v43", GRD)                                     \
+    NB_PRE(PX, PY, PZ, "v17", "v18", "v19", "v44", "v45", "v46", "v47", GRD)                                     \
+    NB_PRE(PX, PY, PZ, "v21", "v22", "v23", "v48", "v49", "v50", "v51", GRD)                                     \
+    "v_rsq_f32_e32 v36, v36\n\tv_rsq_f32_e32 v40, v40\n\tv_rsq_f32_e32 v44, v44\n\tv_rsq_f32_e32 v48, v48\n\t"       \
+    NEXT "s_nop 15\n\ts_nop 11\n\t"                                                                              \
+    NB_POST(PM, "v12", "v25", "v26", "v36", "v37", "v38", "v39", "v33")                                          \
+    NB_POST(PM, "v16", "v27", "v28", "v40", "v41", "v42", "v43", "v34")                                          \
+    NB_POST(PM, "v20", "v29", "v30", "v44", "v45", "v46", "v47", "v33")                                          \
+    NB_POST(PM, "v24", "v31", "v32", "v48", "v49", "v50", "v51", "v34")
+#define NB_TILE_LOOP(GRD)                                                                                        \
+    "ds_read_b128 v[0:3], v52\n\t"                                                                               \
+    "s_mov_b32 %[cnt], 64\n"                                                                                     \
+    "1:\n\t"                                                                                                     \
+    NB_COLUMN("v0", "v1", "v2", "v3", "ds_read_b128 v[4:7], v52 offset:16\n\t", GRD)                             \
+    NB_COLUMN("v4", "v5", "v6", "v7", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD)                             \
+    NB_COLUMN("v0", "v1", "v2", "v3", "ds_read_b128 v[4:7], v52 offset:48\n\t", GRD)                             \
+    NB_COLUMN("v4", "v5", "v6", "v7", "v_add_u32_e32 v52, 64, v52\n\tds_read_b128 v[0:3], v52\n\t", GRD)          \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_waitcnt lgkmcnt(0)\n"
+
+template <bool GUARD>
+__global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
+{
+    __shared__ float4 tile[2 * kTile + 1];  // + 1: the loop's last read-ahead lands one body past the second tile
+
+    const int tid = threadIdx.x;
+    int split = a.split_first + blockIdx.y;
+    if (split >= a.skip_first)
+        split += a.skip_count;
+    const int j0 = split * a.split_len;
+    const int j1 = min(j0 + a.split_len, a.n_total);
+    const int ntiles = (j1 - j0 + kTile - 1) / kTile;
+    const int row_base = blockIdx.x * (kTile * 4) + tid;
+
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
+    {
+        float4 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = row_base + k * kTile;
+            p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.row_count)
+                p[k] = a.pos[a.row_lo + r];
+        }
+        x0 = p[0].x; y0 = p[0].y; z0 = p[0].z;
+        x1 = p[1].x; y1 = p[1].y; z1 = p[1].z;
+        x2 = p[2].x; y2 = p[2].y; z2 = p[2].z;
+        x3 = p[3].x; y3 = p[3].y; z3 = p[3].z;
+    }
+    float ax0 = 0.f, ay0 = 0.f, az0 = 0.f, ax1 = 0.f, ay1 = 0.f, az1 = 0.f;
+    float ax2 = 0.f, ay2 = 0.f, az2 = 0.f, ax3 = 0.f, ay3 = 0.f, az3 = 0.f;
+    const float eps2 = a.eps2;
+
+    float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j0 + tid < j1)
+        stage = a.pos[j0 + tid];
+    tile[tid] = stage;
+    if (tid == 0)
+        tile[2 * kTile] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int jn = j0 + (t + 1) * kTile + tid;
+        if (t + 1 < ntiles) {  // in flight under the tile's arithmetic
+            stage = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jn < j1)
+                stage = a.pos[jn];
+        }
+        unsigned lds = (unsigned)(size_t)(&tile[(t & 1) * kTile]);  // LDS byte address of the current tile
+        unsigned cnt;
+        if (GUARD) {
+            const float tiny = 1.0e-24f;
+            asm volatile(NB_TILE_LOOP(NB_GUARD)
+                         : "+{v12}"(ax0), "+{v25}"(ay0), "+{v26}"(az0), "+{v16}"(ax1), "+{v27}"(ay1), "+{v28}"(az1),
+                           "+{v20}"(ax2), "+{v29}"(ay2), "+{v30}"(az2), "+{v24}"(ax3), "+{v31}"(ay3), "+{v32}"(az3),
+                           "+{v52}"(lds), [cnt] "=&s"(cnt)
+                         : "{v9}"(x0), "{v10}"(y0), "{v11}"(z0), "{v13}"(x1), "{v14}"(y1), "{v15}"(z1), "{v17}"(x2),
+                           "{v18}"(y2), "{v19}"(z2), "{v21}"(x3), "{v22}"(y3), "{v23}"(z3), "{v8}"(eps2), "{v35}"(tiny)
+                         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40",
+                           "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "memory");
+        } else {
+            asm volatile(NB_TILE_LOOP(NB_NOGUARD)
+                         : "+{v12}"(ax0), "+{v25}"(ay0), "+{v26}"(az0), "+{v16}"(ax1), "+{v27}"(ay1), "+{v28}"(az1),
+                           "+{v20}"(ax2), "+{v29}"(ay2), "+{v30}"(az2), "+{v24}"(ax3), "+{v31}"(ay3), "+{v32}"(az3),
+                           "+{v52}"(lds), [cnt] "=&s"(cnt)
+                         : "{v9}"(x0), "{v10}"(y0), "{v11}"(z0), "{v13}"(x1), "{v14}"(y1), "{v15}"(z1), "{v17}"(x2),
+                           "{v18}"(y2), "{v19}"(z2), "{v21}"(x3), "{v22}"(y3), "{v23}"(z3), "{v8}"(eps2)
+                         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40",
+                           "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "memory");
+        }
+        if (t + 1 < ntiles)
+            tile[((t + 1) & 1) * kTile + tid] = stage;
+        __syncthreads();
+    }
+
+    float4 *out = a.partials + (size_t)split * a.row_count;
+    const float4 r0 = make_float4(ax0, ay0, az0, 0.f), r1 = make_float4(ax1, ay1, az1, 0.f);
+    const float4 r2 = make_float4(ax2, ay2, az2, 0.f), r3 = make_float4(ax3, ay3, az3, 0.f);
+    if (row_base < a.row_count) out[row_base] = r0;
+    if (row_base + kTile < a.row_count) out[row_base + kTile] = r1;
+    if (row_base + 2 * kTile < a.row_count) out[row_base + 2 * kTile] = r2;
+    if (row_base + 3 * kTile < a.row_count) out[row_base + 3 * kTile] = r3;
+}
+
 template <int RPL>
 static hipError_t launch_forces_rpl(const ForceArgs &a, hipStream_t stream)
 {
@@ -117,6 +268,17 @@ static hipError_t launch_forces_rpl(const ForceArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+static hipError_t launch_forces_r4_asm(const ForceArgs &a, hipStream_t stream)
+{
+    dim3 grid((a.row_count + kTile * 4 - 1) / (kTile * 4), a.split_count, 1);
+    if (a.eps2 > 0.f)
+        hipLaunchKernelGGL(force_kernel_r4<false>, grid, dim3(kTile), 0, stream, a);
+    else
+        hipLaunchKernelGGL(force_kernel_r4<true>, grid, dim3(kTile), 0, stream, a);
+    return hipGetLastError();
+}
+
+// rows_per_lane: 4 = the hand-allocated kernel (default), 1/2/8 and -4 = the compiler-allocated template
 hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stream)
 {
     if (a.row_count <= 0 || a.split_count <= 0)
@@ -124,7 +286,8 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
     switch (rows_per_lane) {
     case 1: return launch_forces_rpl<1>(a, stream);
     case 2: return launch_forces_rpl<2>(a, stream);
-    case 4: return launch_forces_rpl<4>(a, stream);
+    case 4: return launch_forces_r4_asm(a, stream);
+    case -4: return launch_forces_rpl<4>(a, stream);
     case 8: return launch_forces_rpl<8>(a, stream);
     default: return hipErrorInvalidValue;
     }

@@ -138,7 +138,7 @@ def test_reference_constants_and_padding(nb, oracle_mod):
 def test_register_blocking_is_bit_exact(nb):
     pos, vel = nb.plummer(10000, seed=31)
     ref = None
-    for rpl in (1, 2, 4, 8):
+    for rpl in (1, 2, 4, -4, 8):      # 4 = the hand-allocated inner loop, -4 = the compiled one
         with nb.NBodySystem(pos.shape[0]) as s:
             s.set_rows_per_lane(rpl)
             s.setParticlesPosition(pos)

@@ -22,6 +22,19 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, unsigned ticks
     while (__builtin_amdgcn_s_memrealtime() - r0 < ticks) {
         if (mode == 3) {
             asm volatile(P_RSQ REP8(P_FMAC) ::: CLOB);
+        } else if (mode == 4) {
+            asm volatile(P_RSQ "s_sleep 1\n" REP8(P_FMAC) ::: CLOB);
+        } else if (mode == 5) {
+            asm volatile(P_RSQ "s_sleep 2\n" REP8(P_FMAC) ::: CLOB);
+        } else if (mode == 6) {
+            asm volatile(P_RSQ "s_sleep 4\n" REP8(P_FMAC) ::: CLOB);
+        } else if (mode == 7) {
+            asm volatile(P_RSQ "s_nop 15\n s_nop 15\n" REP8(P_FMAC) ::: CLOB);
+        } else if (mode == 8) {  // consume every rsq result right after the batch
+            asm volatile(P_RSQ "v_add_f32 v2, v24, v25\n v_add_f32 v2, v26, v27\n v_add_f32 v2, v28, v29\n v_add_f32 v2, v30, v31\n" REP8(P_FMAC) ::: CLOB, "v2");
+        } else if (mode == 9) {  // one rsq spread between fmac groups
+            asm volatile("v_rsq_f32_e32 v24, v24\n" P_FMAC "v_rsq_f32_e32 v25, v25\n" P_FMAC "v_rsq_f32_e32 v26, v26\n" P_FMAC "v_rsq_f32_e32 v27, v27\n" P_FMAC
+                         "v_rsq_f32_e32 v28, v28\n" P_FMAC "v_rsq_f32_e32 v29, v29\n" P_FMAC "v_rsq_f32_e32 v30, v30\n" P_FMAC "v_rsq_f32_e32 v31, v31\n" P_FMAC ::: CLOB);
         } else if (rsq_role) {
             asm volatile(REP8(P_RSQ) ::: CLOB);
         } else {
@@ -44,8 +57,8 @@ int main()
     unsigned long long *dev;
     (void)hipMalloc((void **)&dev, sizeof(unsigned long long) * cus * 8 * 4 * 2);
     std::vector<unsigned long long> h((size_t)cus * 8 * 4 * 2);
-    for (int bpc : {2, 4, 8})
-        for (int mode : {0, 1, 2, 3}) {
+    for (int bpc : {4, 8})
+        for (int mode : {0, 3, 4, 5, 6, 7, 8, 9}) {
             const int blocks = cus * bpc, nw = blocks * 4;
             hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, dev, 2000u, mode);
             hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, dev, 30000u, mode);
@@ -61,9 +74,9 @@ int main()
             printf("blk/CU=%d mode=%d:", bpc, mode);
             for (int role = 0; role < 2; ++role)
                 if (cnt[role]) {
-                    const double instr = b[role] * (mode == 3 ? 72.0 : 64.0);
+                    const double instr = b[role] * (mode >= 3 ? 72.0 : 64.0);
                     // instructions of this role per SIMD cycle (all SIMDs, mean elapsed cycles)
-                    printf("  %s: %.3f instr/SIMD-cycle (%.2f cyc/instr)", role ? "rsq " : (mode == 3 ? "mixed 8 rsq + 64 fmac" : "fmac"),
+                    printf("  %s: %.3f instr/SIMD-cycle (%.2f cyc/instr)", role ? "rsq " : (mode >= 3 ? "8 rsq + 64 fmac, cycles per body/72" : "fmac"),
                            instr / (simds * c[role] / cnt[role]), simds * c[role] / cnt[role] / instr);
                 }
             printf("\n");
