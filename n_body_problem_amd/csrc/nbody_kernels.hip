@@ -146,7 +146,8 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 #define NB_POST(PM, AX, AY, AZ, R, D0, D1, D2, Q)                                                                \
     "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " R ", " PM ", " R "\n\tv_mul_f32_e32 " R ", " R ", " Q "\n\t"     \
     "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t"
-// one column: wait for its LDS read, phase 1 for the four rows, the four rsq, issue the NEXT read, idle, phase 4
+// one column: wait for its LDS read, phase 1 for the four rows, the four rsq, issue the NEXT read, idle 24 wait
+// states (20-28 measured equally good on the kernel, 12 and 32 about 2 % worse), phase 4
 #define NB_COLUMN(PX, PY, PZ, PM, NEXT, GRD)                                                                     \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
     NB_PRE(PX, PY, PZ, "v9", "v10", "v11", "v36", "v37", "v38", "v39", GRD)                                      \
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     NB_PRE(PX, PY, PZ, "v17", "v18", "v19", "v44", "v45", "v46", "v47", GRD)                                     \
     NB_PRE(PX, PY, PZ, "v21", "v22", "v23", "v48", "v49", "v50", "v51", GRD)                                     \
     "v_rsq_f32_e32 v36, v36\n\tv_rsq_f32_e32 v40, v40\n\tv_rsq_f32_e32 v44, v44\n\tv_rsq_f32_e32 v48, v48\n\t"       \
-    NEXT "s_nop 15\n\ts_nop 11\n\t"                                                                              \
+    NEXT "s_nop 15\n\ts_nop 7\n\t"                                                                               \
     NB_POST(PM, "v12", "v25", "v26", "v36", "v37", "v38", "v39", "v33")                                          \
     NB_POST(PM, "v16", "v27", "v28", "v40", "v41", "v42", "v43", "v34")                                          \
     NB_POST(PM, "v20", "v29", "v30", "v44", "v45", "v46", "v47", "v33")                                          \
@@ -186,7 +187,15 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     const int ntiles = (j1 - j0 + kTile - 1) / kTile;
     const int row_base = blockIdx.x * (kTile * 4) + tid;
 
-    float x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
+    // pinned for the whole kernel (local register variables): no copies around the asm block, 8 waves per SIMD
+    register float x0 asm("v9"), y0 asm("v10"), z0 asm("v11"), ax0 asm("v12");
+    register float x1 asm("v13"), y1 asm("v14"), z1 asm("v15"), ax1 asm("v16");
+    register float x2 asm("v17"), y2 asm("v18"), z2 asm("v19"), ax2 asm("v20");
+    register float x3 asm("v21"), y3 asm("v22"), z3 asm("v23"), ax3 asm("v24");
+    register float ay0 asm("v25"), az0 asm("v26"), ay1 asm("v27"), az1 asm("v28");
+    register float ay2 asm("v29"), az2 asm("v30"), ay3 asm("v31"), az3 asm("v32");
+    register float eps2 asm("v8");
+    register float tiny asm("v35");
     {
         float4 p[4];
 #pragma unroll
@@ -201,9 +210,9 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
         x2 = p[2].x; y2 = p[2].y; z2 = p[2].z;
         x3 = p[3].x; y3 = p[3].y; z3 = p[3].z;
     }
-    float ax0 = 0.f, ay0 = 0.f, az0 = 0.f, ax1 = 0.f, ay1 = 0.f, az1 = 0.f;
-    float ax2 = 0.f, ay2 = 0.f, az2 = 0.f, ax3 = 0.f, ay3 = 0.f, az3 = 0.f;
-    const float eps2 = a.eps2;
+    ax0 = ay0 = az0 = ax1 = ay1 = az1 = ax2 = ay2 = az2 = ax3 = ay3 = az3 = 0.f;
+    eps2 = a.eps2;
+    tiny = 1.0e-24f;
 
     float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j0 + tid < j1)
@@ -220,28 +229,20 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
             if (jn < j1)
                 stage = a.pos[jn];
         }
-        unsigned lds = (unsigned)(size_t)(&tile[(t & 1) * kTile]);  // LDS byte address of the current tile
+        register unsigned lds asm("v52") = (unsigned)(size_t)(&tile[(t & 1) * kTile]);  // LDS byte address of the tile
         unsigned cnt;
-        if (GUARD) {
-            const float tiny = 1.0e-24f;
-            asm volatile(NB_TILE_LOOP(NB_GUARD)
-                         : "+{v12}"(ax0), "+{v25}"(ay0), "+{v26}"(az0), "+{v16}"(ax1), "+{v27}"(ay1), "+{v28}"(az1),
-                           "+{v20}"(ax2), "+{v29}"(ay2), "+{v30}"(az2), "+{v24}"(ax3), "+{v31}"(ay3), "+{v32}"(az3),
-                           "+{v52}"(lds), [cnt] "=&s"(cnt)
-                         : "{v9}"(x0), "{v10}"(y0), "{v11}"(z0), "{v13}"(x1), "{v14}"(y1), "{v15}"(z1), "{v17}"(x2),
-                           "{v18}"(y2), "{v19}"(z2), "{v21}"(x3), "{v22}"(y3), "{v23}"(z3), "{v8}"(eps2), "{v35}"(tiny)
-                         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40",
-                           "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "memory");
-        } else {
-            asm volatile(NB_TILE_LOOP(NB_NOGUARD)
-                         : "+{v12}"(ax0), "+{v25}"(ay0), "+{v26}"(az0), "+{v16}"(ax1), "+{v27}"(ay1), "+{v28}"(az1),
-                           "+{v20}"(ax2), "+{v29}"(ay2), "+{v30}"(az2), "+{v24}"(ax3), "+{v31}"(ay3), "+{v32}"(az3),
-                           "+{v52}"(lds), [cnt] "=&s"(cnt)
-                         : "{v9}"(x0), "{v10}"(y0), "{v11}"(z0), "{v13}"(x1), "{v14}"(y1), "{v15}"(z1), "{v17}"(x2),
-                           "{v18}"(y2), "{v19}"(z2), "{v21}"(x3), "{v22}"(y3), "{v23}"(z3), "{v8}"(eps2)
-                         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40",
-                           "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "memory");
-        }
+#define NB_OPERANDS                                                                                                   \
+        : "+v"(ax0), "+v"(ay0), "+v"(az0), "+v"(ax1), "+v"(ay1), "+v"(az1), "+v"(ax2), "+v"(ay2), "+v"(az2), "+v"(ax3),    \
+          "+v"(ay3), "+v"(az3), "+v"(lds), [cnt] "=&s"(cnt)                                                             \
+        : "v"(x0), "v"(y0), "v"(z0), "v"(x1), "v"(y1), "v"(z1), "v"(x2), "v"(y2), "v"(z2), "v"(x3), "v"(y3), "v"(z3),      \
+          "v"(eps2), "v"(tiny)                                                                                          \
+        : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42",   \
+          "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "memory"
+        if (GUARD)
+            asm volatile(NB_TILE_LOOP(NB_GUARD) NB_OPERANDS);
+        else
+            asm volatile(NB_TILE_LOOP(NB_NOGUARD) NB_OPERANDS);
+#undef NB_OPERANDS
         if (t + 1 < ntiles)
             tile[((t + 1) & 1) * kTile + tid] = stage;
         __syncthreads();
