@@ -52,7 +52,9 @@ def main(tag, rnd, n):
         cyc = mean["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
         out["effective_clock_GHz"] = cyc / (out["avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
         if "SQ_ACTIVE_INST_VALU" in mean:
-            out["valu_busy_fraction"] = mean["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)   # quad-cycles, 1024 SIMDs
+            # wave-cycles with a VALU instruction in flight per SIMD cycle (quad-cycle counter; > 1 when several waves
+            # of a SIMD overlap): not a utilisation fraction
+            out["valu_active_wave_cycles_per_simd_cycle"] = mean["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
         if "SQ_WAVE_CYCLES" in mean:
             out["mean_waves_per_simd"] = mean["SQ_WAVE_CYCLES"] * 4.0 / (cyc * 1024.0)
         if "SQ_INSTS_VALU" in mean:
