@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--softening", type=float, default=1e-3)
     ap.add_argument("--split-len", type=int, default=0)
+    ap.add_argument("--symmetric", action="store_true", help="time the experimental pair-once kernel (rpl is ignored)")
     args = ap.parse_args()
 
     import torch
@@ -55,6 +56,8 @@ def main():
         assert rc == 0, lib.nbody_last_error(None)
         lib.nbody_set_stream(ctx, stream)
         lib.nbody_timing_enable(ctx, 1)
+        if args.symmetric:
+            assert lib.nbody_set_force_mode(ctx, 1) == 0, lib.nbody_last_error(ctx)
         for rpl in [int(x) for x in args.rpl.split(",")]:
             variants.append((f"{name}/rpl{rpl}", lib, ctx, rpl))
 
