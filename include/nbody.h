@@ -112,6 +112,22 @@ int nbody_forces_complement(nbody_ctx *ctx, const float *d_positions_xyzm, int64
                             float softening);
 int nbody_update(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, float dt);
 
+/* ---- integrator ----
+ * NBODY_INTEGRATOR_KICK_DRIFT (default): the reference's final scheme, v += a(x) dt ; x += v dt (kernel.cu:777-801).
+ * NBODY_INTEGRATOR_KDK: velocity Verlet, v += a dt/2 ; x += v dt ; v += a(x_new) dt/2 -- the scheme of the reference's
+ *   historical update_speed_half / update_position_complete (unused_files/backup.cu:859-887, driven at :1848-1866
+ *   with TWO force evaluations per step); here the accelerations are cached, one evaluation per step.  nbody_step
+ *   / nbody_step_n follow the selected integrator; positions changed behind the library's back (a new buffer, an
+ *   edit) need nbody_invalidate_forces.  A sharded host drives the pieces itself, because the drifted rows must be
+ *   exchanged before the forces: forces + nbody_kdk_prepare once, then per step nbody_kdk_kick_drift -> exchange ->
+ *   nbody_forces (+ _complement) -> nbody_kdk_kick. */
+enum { NBODY_INTEGRATOR_KICK_DRIFT = 0, NBODY_INTEGRATOR_KDK = 1 };
+int nbody_set_integrator(nbody_ctx *ctx, int integrator);
+int nbody_invalidate_forces(nbody_ctx *ctx);
+int nbody_kdk_prepare(nbody_ctx *ctx);
+int nbody_kdk_kick_drift(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, float dt);
+int nbody_kdk_kick(nbody_ctx *ctx, float *d_velocities_xyzw, float dt);
+
 /* nbody_set_stream: enqueue on the caller's HIP stream (a hipStream_t passed as void*, used verbatim: NULL is
  * the HIP default stream).  nbody_reset_stream: back to the context's own non-blocking stream (the default). */
 int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);

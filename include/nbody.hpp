@@ -65,6 +65,16 @@ public:
         check(nbody_step(ctx_, dPositions, dVelocities, dMasses, dt, softening), "nbody_step");
     }
     void stepN(int k, float dt, float softening) { check(nbody_step_n(ctx_, k, dt, softening), "nbody_step_n"); }
+    // false: the reference's kick-drift (kernel.cu:777-801); true: velocity Verlet with cached accelerations
+    void setKickDriftKick(bool on)
+    {
+        check(nbody_set_integrator(ctx_, on ? NBODY_INTEGRATOR_KDK : NBODY_INTEGRATOR_KICK_DRIFT), "nbody_set_integrator");
+    }
+    // experimental pair-once force kernel (single context, 1024 <= split_len <= 8192)
+    void setPairOnce(bool on)
+    {
+        check(nbody_set_force_mode(ctx_, on ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED), "nbody_set_force_mode");
+    }
 
     struct Energy { double kinetic, potential, total; };
     Energy energy(float softening)

@@ -49,6 +49,11 @@ _PROTOTYPES = {
     "nbody_forces": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "nbody_forces_complement": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "nbody_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float]),
+    "nbody_set_integrator": (c_int, [c_void_p, c_int]),
+    "nbody_invalidate_forces": (c_int, [c_void_p]),
+    "nbody_kdk_prepare": (c_int, [c_void_p]),
+    "nbody_kdk_kick_drift": (c_int, [c_void_p, c_void_p, c_void_p, c_float]),
+    "nbody_kdk_kick": (c_int, [c_void_p, c_void_p, c_float]),
     "nbody_set_stream": (c_int, [c_void_p, c_void_p]),
     "nbody_reset_stream": (c_int, [c_void_p]),
     "nbody_energy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, POINTER(c_double)]),

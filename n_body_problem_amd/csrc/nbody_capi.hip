@@ -18,6 +18,9 @@ struct nbody_ctx {
     int n_splits = 0;
     int rows_per_lane = 0;  // 0 = pick per launch
     int force_mode = NBODY_FORCE_ONE_SIDED;
+    int integrator = NBODY_INTEGRATOR_KICK_DRIFT;
+    float4 *acc = nullptr;      // kick-drift-kick mode: accelerations of the own rows at the current positions
+    bool acc_valid = false;
     int2 *sym_tiles = nullptr;  // pair-once mode: the (I <= J) split pairs, one workgroup each
     int sym_n_tiles = 0;
     int cu_count = 256;
@@ -184,6 +187,7 @@ int nbody_destroy(nbody_ctx *c)
     if (c->vel) (void)hipFree(c->vel);
     if (c->reduce_dev) (void)hipFree(c->reduce_dev);
     if (c->sym_tiles) (void)hipFree(c->sym_tiles);
+    if (c->acc) (void)hipFree(c->acc);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return NBODY_OK;
@@ -228,6 +232,7 @@ int nbody_set_positions(nbody_ctx *c, const float *host)
         HIP_TRY(c, hipMemcpyAsync(c->pos, host, sizeof(float4) * (size_t)c->n_total, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    c->acc_valid = false;
     return NBODY_OK;
 }
 
@@ -490,6 +495,109 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
     return NBODY_OK;
 }
 
+// ---- kick-drift-kick (velocity Verlet) with cached accelerations ----------------------------------------------
+
+static int all_splits_done(nbody_ctx *c, const char *who)
+{
+    for (int s = 0; s < c->n_splits; ++s)
+        if (!c->split_done[(size_t)s])
+            return fail(c, NBODY_ERR_STATE, std::string(who) + ": split " + std::to_string(s) +
+                                                " has no partial sums (call nbody_forces for every column range first)");
+    return NBODY_OK;
+}
+
+static int ensure_acc(nbody_ctx *c)
+{
+    if (!c->acc && c->row_count) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipMalloc((void **)&c->acc, sizeof(float4) * (size_t)c->row_count));
+    }
+    return NBODY_OK;
+}
+
+int nbody_set_integrator(nbody_ctx *c, int integrator)
+{
+    if (!c || (integrator != NBODY_INTEGRATOR_KICK_DRIFT && integrator != NBODY_INTEGRATOR_KDK))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_integrator: unknown integrator");
+    c->integrator = integrator;
+    c->acc_valid = false;
+    return NBODY_OK;
+}
+
+int nbody_invalidate_forces(nbody_ctx *c)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    c->acc_valid = false;
+    return NBODY_OK;
+}
+
+int nbody_kdk_prepare(nbody_ctx *c)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    if (c->row_count == 0) {
+        c->acc_valid = true;
+        return NBODY_OK;
+    }
+    int rc = all_splits_done(c, "nbody_kdk_prepare");
+    if (rc == NBODY_OK)
+        rc = ensure_acc(c);
+    if (rc != NBODY_OK)
+        return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_kdk_reduce(c->acc, c->partials, (int)c->row_count, c->n_splits, c->stream));
+    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    c->acc_valid = true;
+    return NBODY_OK;
+}
+
+int nbody_kdk_kick_drift(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
+{
+    if (!c || ((!d_pos || !d_vel) && c->row_count))
+        return fail(c, NBODY_ERR_INVALID, "nbody_kdk_kick_drift: NULL argument");
+    if (!std::isfinite(dt))
+        return fail(c, NBODY_ERR_INVALID, "nbody_kdk_kick_drift: dt must be finite");
+    if (!c->acc_valid)
+        return fail(c, NBODY_ERR_STATE, "nbody_kdk_kick_drift: no cached accelerations (nbody_forces + nbody_kdk_prepare first)");
+    if (c->row_count == 0)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        TimedLaunch t(c, &c->ev_update);
+        HIP_TRY(c, launch_kdk_kick_drift(reinterpret_cast<float4 *>(d_pos), reinterpret_cast<float4 *>(d_vel), c->acc,
+                                         (int)c->row_lo, (int)c->row_count, dt, c->stream));
+    }
+    c->acc_valid = false;  // the positions moved: a kick must follow
+    return NBODY_OK;
+}
+
+int nbody_kdk_kick(nbody_ctx *c, float *d_vel, float dt)
+{
+    if (!c || (!d_vel && c->row_count))
+        return fail(c, NBODY_ERR_INVALID, "nbody_kdk_kick: NULL argument");
+    if (!std::isfinite(dt))
+        return fail(c, NBODY_ERR_INVALID, "nbody_kdk_kick: dt must be finite");
+    if (c->row_count == 0) {
+        c->acc_valid = true;
+        return NBODY_OK;
+    }
+    int rc = all_splits_done(c, "nbody_kdk_kick");
+    if (rc == NBODY_OK)
+        rc = ensure_acc(c);
+    if (rc != NBODY_OK)
+        return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        TimedLaunch t(c, &c->ev_update);
+        HIP_TRY(c, launch_kdk_kick(reinterpret_cast<float4 *>(d_vel), c->acc, c->partials, (int)c->row_count, c->n_splits, dt,
+                                   c->stream));
+    }
+    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    c->acc_valid = true;
+    return NBODY_OK;
+}
+
 int nbody_step_async(nbody_ctx *c, float *d_pos, float *d_vel, const float *d_masses, float dt, float softening)
 {
     if (!c)
@@ -499,12 +607,32 @@ int nbody_step_async(nbody_ctx *c, float *d_pos, float *d_vel, const float *d_ma
     if (d_masses) {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, launch_scatter_mass(reinterpret_cast<float4 *>(d_pos), d_masses, (int)c->n_total, c->stream));
+        c->acc_valid = false;
     }
-    int rc = nbody_forces(c, d_pos, 0, c->n_total, softening);
-    if (rc != NBODY_OK)
-        return rc;
     if (c->n_total == 0)
         return NBODY_OK;
+    int rc;
+    if (c->integrator == NBODY_INTEGRATOR_KDK) {
+        if (c->row_lo != 0 || c->row_count != c->n_total)
+            return fail(c, NBODY_ERR_INVALID, "nbody_step: a sharded context drives kick-drift-kick through nbody_kdk_* "
+                                              "(the drift must be exchanged before the forces)");
+        if (!c->acc_valid) {
+            rc = nbody_forces(c, d_pos, 0, c->n_total, softening);
+            if (rc == NBODY_OK)
+                rc = nbody_kdk_prepare(c);
+            if (rc != NBODY_OK)
+                return rc;
+        }
+        rc = nbody_kdk_kick_drift(c, d_pos, d_vel, dt);
+        if (rc == NBODY_OK)
+            rc = nbody_forces(c, d_pos, 0, c->n_total, softening);
+        if (rc == NBODY_OK)
+            rc = nbody_kdk_kick(c, d_vel, dt);
+        return rc;
+    }
+    rc = nbody_forces(c, d_pos, 0, c->n_total, softening);
+    if (rc != NBODY_OK)
+        return rc;
     return nbody_update(c, d_pos, d_vel, dt);
 }
 

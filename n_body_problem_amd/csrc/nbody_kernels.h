@@ -43,6 +43,17 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
 hipError_t launch_update(float4 *pos_all, float4 *vel_rows, const float4 *partials, int row_lo, int row_count,
                          int n_splits, float dt, hipStream_t stream);
 
+// Velocity-Verlet (kick-drift-kick) pieces with cached accelerations (the reference's historical
+// variant, unused_files/backup.cu:859-887 driven at :1848-1866, spends two force evaluations per step).
+//   reduce    : acc[r] = sum of the splits' partials, ascending                              (first step only)
+//   kick_drift: v += acc*dt/2 ; x += v*dt                                                   (fp64 FMA, as the update)
+//   kick      : acc[r] = sum of partials ; v += acc*dt/2
+hipError_t launch_kdk_reduce(float4 *acc, const float4 *partials, int row_count, int n_splits, hipStream_t stream);
+hipError_t launch_kdk_kick_drift(float4 *pos_all, float4 *vel_rows, const float4 *acc, int row_lo, int row_count, float dt,
+                                 hipStream_t stream);
+hipError_t launch_kdk_kick(float4 *vel_rows, float4 *acc, const float4 *partials, int row_count, int n_splits, float dt,
+                           hipStream_t stream);
+
 // positions[4i+3] = masses[i]
 hipError_t launch_scatter_mass(float4 *pos_all, const float *masses, int n_total, hipStream_t stream);
 

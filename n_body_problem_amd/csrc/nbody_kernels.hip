@@ -294,6 +294,18 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
     }
 }
 
+__device__ __forceinline__ float4 sum_partials(const float4 *partials, int r, int row_count, int n_splits)
+{
+    float4 acc = partials[r];
+    for (int s = 1; s < n_splits; ++s) {
+        const float4 p = partials[(size_t)s * row_count + r];
+        acc.x += p.x;
+        acc.y += p.y;
+        acc.z += p.z;
+    }
+    return acc;
+}
+
 // use_acc_update_position, kernel.cu:777-801, with the reference's fp64 FMA (TIME_TICK is a double
 // literal there) and the partial sums of the splits added first, in ascending split order.
 __global__ __launch_bounds__(kTile) void update_kernel(float4 *pos_all, float4 *vel_rows, const float4 *partials,
@@ -302,13 +314,7 @@ __global__ __launch_bounds__(kTile) void update_kernel(float4 *pos_all, float4 *
     const int r = blockIdx.x * kTile + threadIdx.x;
     if (r >= row_count)
         return;
-    float4 acc = partials[r];
-    for (int s = 1; s < n_splits; ++s) {
-        const float4 p = partials[(size_t)s * row_count + r];
-        acc.x += p.x;
-        acc.y += p.y;
-        acc.z += p.z;
-    }
+    const float4 acc = sum_partials(partials, r, row_count, n_splits);
     float4 v = vel_rows[r];
     float4 x = pos_all[row_lo + r];
     const double h = (double)dt;
@@ -329,6 +335,75 @@ hipError_t launch_update(float4 *pos_all, float4 *vel_rows, const float4 *partia
         return hipSuccess;
     hipLaunchKernelGGL(update_kernel, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, pos_all,
                        vel_rows, partials, row_lo, row_count, n_splits, dt);
+    return hipGetLastError();
+}
+
+// mode 0: acc = sum ; mode 1: acc = sum, v += acc*dt/2
+template <int MODE>
+__global__ __launch_bounds__(kTile) void kdk_kick_kernel(float4 *vel_rows, float4 *acc_out, const float4 *partials,
+                                                         int row_count, int n_splits, float dt)
+{
+    const int r = blockIdx.x * kTile + threadIdx.x;
+    if (r >= row_count)
+        return;
+    const float4 acc = sum_partials(partials, r, row_count, n_splits);
+    acc_out[r] = acc;
+    if (MODE == 1) {
+        float4 v = vel_rows[r];
+        const double h = 0.5 * (double)dt;
+        v.x = (float)__builtin_fma((double)acc.x, h, (double)v.x);
+        v.y = (float)__builtin_fma((double)acc.y, h, (double)v.y);
+        v.z = (float)__builtin_fma((double)acc.z, h, (double)v.z);
+        vel_rows[r] = v;
+    }
+}
+
+__global__ __launch_bounds__(kTile) void kdk_kick_drift_kernel(float4 *pos_all, float4 *vel_rows, const float4 *acc_in,
+                                                               int row_lo, int row_count, float dt)
+{
+    const int r = blockIdx.x * kTile + threadIdx.x;
+    if (r >= row_count)
+        return;
+    const float4 acc = acc_in[r];
+    float4 v = vel_rows[r];
+    float4 x = pos_all[row_lo + r];
+    const double h = (double)dt, hh = 0.5 * (double)dt;
+    v.x = (float)__builtin_fma((double)acc.x, hh, (double)v.x);
+    v.y = (float)__builtin_fma((double)acc.y, hh, (double)v.y);
+    v.z = (float)__builtin_fma((double)acc.z, hh, (double)v.z);
+    x.x = (float)__builtin_fma((double)v.x, h, (double)x.x);
+    x.y = (float)__builtin_fma((double)v.y, h, (double)x.y);
+    x.z = (float)__builtin_fma((double)v.z, h, (double)x.z);
+    vel_rows[r] = v;
+    pos_all[row_lo + r] = x;
+}
+
+hipError_t launch_kdk_reduce(float4 *acc, const float4 *partials, int row_count, int n_splits, hipStream_t stream)
+{
+    if (row_count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(kdk_kick_kernel<0>, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, nullptr, acc,
+                       partials, row_count, n_splits, 0.f);
+    return hipGetLastError();
+}
+
+hipError_t launch_kdk_kick(float4 *vel_rows, float4 *acc, const float4 *partials, int row_count, int n_splits, float dt,
+                           hipStream_t stream)
+{
+    if (row_count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(kdk_kick_kernel<1>, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, vel_rows, acc,
+                       partials, row_count, n_splits, dt);
+    return hipGetLastError();
+}
+
+hipError_t launch_kdk_kick_drift(float4 *pos_all, float4 *vel_rows, const float4 *acc, int row_lo, int row_count, float dt,
+                                 hipStream_t stream)
+{
+    if (row_count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(kdk_kick_drift_kernel, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, pos_all,
+                       vel_rows, acc, row_lo, row_count, dt);
     return hipGetLastError();
 }
 

@@ -50,13 +50,17 @@ class ShardedNBodySystem:
     """
 
     def __init__(self, num_bodies: int, group=None, device: Optional[int] = None, exchange: str = "allgather",
-                 kernels_factory: Optional[Callable] = None, split_len: int = 0):
+                 kernels_factory: Optional[Callable] = None, split_len: int = 0, integrator: str = "kick_drift"):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
         if exchange not in ("allgather", "ring"):
             raise ValueError("exchange must be 'allgather' or 'ring'")
+        if integrator not in ("kick_drift", "kdk"):
+            raise ValueError("integrator must be 'kick_drift' or 'kdk'")
         self.exchange = exchange
+        self.integrator = integrator
+        self._kdk_ready = False  # kdk: accelerations at the current positions are cached in the kernels object
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.distributed else 0
@@ -100,6 +104,7 @@ class ShardedNBodySystem:
     def setParticlesPosition(self, data) -> None:
         self._refresh()
         self.positions.copy_(self._torch.from_numpy(self._pad(data)))
+        self._kdk_ready = False
 
     def setParticlesVelocity(self, data) -> None:
         v = self._pad(data)[self.row_lo:self.row_lo + self.chunk]
@@ -183,41 +188,64 @@ class ShardedNBodySystem:
             self._stale = False
 
     # -- the step -------------------------------------------------------------------------------------
-    def step(self, dt: float = _system.TIME_TICK, softening: float = _system.SOFTENING_VERSION3,
-             sync: bool = True) -> None:
+    def _forces_all_columns(self, softening: float) -> None:
+        """Partial sums of the own rows from every column: own chunk first (needs no remote data, so it runs beside
+        the exchange in flight), the other chunks as they become current."""
         k = self.kernels
-        lo, hi = self.row_lo, self.row_lo + self.chunk
+        lo = self.row_lo
         if self._stale:  # ring mode, remote chunks outstanding
-            if self._on_gpu:  # hops may start once the previous update (already enqueued) has written the own rows
+            if self._on_gpu:  # hops may start once the kernel that wrote the own rows (already enqueued) is done
                 self._comm_stream.wait_stream(self._torch.cuda.current_stream(self.positions.device))
             k.forces(lo, self.chunk, softening)              # own chunk: runs beside the first hops
             for _, send_c, recv_c in ring_schedule(self.rank, self.world_size):
                 self._ring_hop(send_c, recv_c)
                 k.forces(recv_c * self.chunk, self.chunk, softening)
             self._stale = False
-        else:
-            torch = self._torch
-            two_streams = self._on_gpu and self.world_size > 1
-            if two_streams:
-                cur = torch.cuda.current_stream(self.positions.device)
-                self._side_stream.wait_stream(cur)           # uploads / the previous update are ordered before it
-            k.forces(lo, self.chunk, softening)              # own chunk: runs beside the all-gather in flight
-            if two_streams:
-                # the other chunks on a second stream: their workgroups fill the CUs the first launch's tail
-                # leaves idle (the launches write disjoint partial sums)
-                with torch.cuda.stream(self._side_stream):
-                    self._drain()                            # this stream, not the host, waits for the exchange
-                    k.forces_complement(lo, self.chunk, softening)
-                cur.wait_stream(self._side_stream)
-            elif self.world_size > 1:
-                self._drain()
+            return
+        torch = self._torch
+        two_streams = self._on_gpu and self.world_size > 1
+        if two_streams:
+            cur = torch.cuda.current_stream(self.positions.device)
+            self._side_stream.wait_stream(cur)           # uploads / the previous update are ordered before it
+        k.forces(lo, self.chunk, softening)              # own chunk: runs beside the all-gather in flight
+        if two_streams:
+            # the other chunks on a second stream: their workgroups fill the CUs the first launch's tail
+            # leaves idle (the launches write disjoint partial sums)
+            with torch.cuda.stream(self._side_stream):
+                self._drain()                            # this stream, not the host, waits for the exchange
                 k.forces_complement(lo, self.chunk, softening)
-        k.update(dt)
+            cur.wait_stream(self._side_stream)
+        elif self.world_size > 1:
+            self._drain()
+            k.forces_complement(lo, self.chunk, softening)
+
+    def _exchange_own_rows(self) -> None:
         if self.world_size > 1:
             if self.exchange == "allgather":
                 self._start_allgather()
             else:
                 self._stale = True
+
+    def step(self, dt: float = _system.TIME_TICK, softening: float = _system.SOFTENING_VERSION3,
+             sync: bool = True) -> None:
+        k = self.kernels
+        if self.integrator == "kdk":
+            # velocity Verlet: the drifted rows are exchanged BEFORE the forces; the own-chunk force kernel still
+            # runs beside the exchange
+            if not self._kdk_ready:
+                self._forces_all_columns(softening)
+                k.kdk_prepare()
+                self._kdk_ready = True
+            k.kdk_kick_drift(dt)
+            self._exchange_own_rows()
+            self._forces_all_columns(softening)
+            k.kdk_kick(dt)
+            if sync:
+                self.sync()
+            return
+        self._forces_all_columns(softening)
+        k.update(dt)
+        self._exchange_own_rows()
         if sync:
             self.sync()
 

@@ -100,6 +100,7 @@ class NBodySystem:
         if a.shape[0] != self.num_bodies:
             raise ValueError(f"expected {self.num_bodies} bodies, got {a.shape[0]}")
         self.positions.copy_(torch.from_numpy(a))
+        self._lib.nbody_invalidate_forces(self._ctx)
 
     def setParticlesVelocity(self, data) -> None:
         """Host ``float4 {vx,vy,vz,eps}`` -> the device velocity buffer.
@@ -161,6 +162,28 @@ class NBodySystem:
 
     def sync(self) -> None:
         check(self._lib.nbody_sync(self._ctx), self._ctx)
+
+    # -- integrator (kick-drift = the reference's final scheme; kdk = velocity Verlet with cached accelerations) ----
+    def set_integrator(self, name: str) -> None:
+        check(self._lib.nbody_set_integrator(self._ctx, {"kick_drift": 0, "kdk": 1}[name]), self._ctx)
+
+    def invalidate_forces(self) -> None:
+        check(self._lib.nbody_invalidate_forces(self._ctx), self._ctx)
+
+    def kdk_prepare(self) -> None:
+        self._use_current_stream()
+        check(self._lib.nbody_kdk_prepare(self._ctx), self._ctx)
+
+    def kdk_kick_drift(self, dt: float, positions=None, velocities=None) -> None:
+        self._use_current_stream()
+        p = self.positions if positions is None else positions
+        v = self.velocities if velocities is None else velocities
+        check(self._lib.nbody_kdk_kick_drift(self._ctx, _ptr(p), _ptr(v), float(dt)), self._ctx)
+
+    def kdk_kick(self, dt: float, velocities=None) -> None:
+        self._use_current_stream()
+        v = self.velocities if velocities is None else velocities
+        check(self._lib.nbody_kdk_kick(self._ctx, _ptr(v), float(dt)), self._ctx)
 
     # -- diagnostics -----------------------------------------------------------------------------
     def energy(self, softening: float) -> np.ndarray:

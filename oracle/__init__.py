@@ -49,6 +49,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_update_f32.restype = None
         L.oracle_step_f32.argtypes = [_f32p, _f32p, _c_int, ctypes.c_float, ctypes.c_float, _c_int, _c_int]
         L.oracle_step_f32.restype = _c_int
+        L.oracle_step_kdk_f32.argtypes = [_f32p, _f32p, _c_int, ctypes.c_float, ctypes.c_float, _c_int, _c_int]
+        L.oracle_step_kdk_f32.restype = _c_int
         L.oracle_step_f64.argtypes = [_f64p, _f64p, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_int]
         L.oracle_step_f64.restype = _c_int
         L.oracle_step_v3.argtypes = [_f32p, _f32p, _c_int, _c_int]
@@ -110,6 +112,16 @@ def step_f32(pos, vel, dt, eps, nsteps=1, threads=None):
     rc = lib().oracle_step_f32(p, v, p.shape[0], float(dt), float(eps), int(nsteps), threads or host_threads())
     if rc != 0:
         raise MemoryError("oracle_step_f32")
+    return p, v
+
+
+def step_kdk_f32(pos, vel, dt, eps, nsteps=1, threads=None):
+    """nsteps kick-drift-kick (velocity Verlet) steps in reference-order fp32; returns new (pos, vel)."""
+    p = _f32(pos).reshape(-1, 4).copy()
+    v = _f32(vel).reshape(-1, 4).copy()
+    rc = lib().oracle_step_kdk_f32(p, v, p.shape[0], float(dt), float(eps), int(nsteps), threads or host_threads())
+    if rc != 0:
+        raise MemoryError("oracle_step_kdk_f32")
     return p, v
 
 

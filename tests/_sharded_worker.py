@@ -50,6 +50,30 @@ class OracleKernels:
         rows = self.positions.numpy()[self.row_lo:self.row_lo + self.rows]
         self.oracle.update_f32(rows, self.velocities.numpy(), acc, dt)
 
+    def _reduce(self):
+        assert sorted(self.partials) == list(range(self.n_splits)), "a split is missing"
+        acc = self.partials[0].copy()
+        for s in range(1, self.n_splits):
+            acc += self.partials[s]
+        self.partials = {}
+        return acc
+
+    def kdk_prepare(self):
+        self.acc = self._reduce()
+
+    def kdk_kick_drift(self, dt, positions=None, velocities=None):
+        rows = self.positions.numpy()[self.row_lo:self.row_lo + self.rows]
+        v = self.velocities.numpy()
+        hh, h = 0.5 * float(np.float32(dt)), float(np.float32(dt))
+        v[:, :3] = (self.acc.astype(np.float64) * hh + v[:, :3].astype(np.float64)).astype(np.float32)
+        rows[:, :3] = (v[:, :3].astype(np.float64) * h + rows[:, :3].astype(np.float64)).astype(np.float32)
+
+    def kdk_kick(self, dt, velocities=None):
+        self.acc = self._reduce()
+        v = self.velocities.numpy()
+        hh = 0.5 * float(np.float32(dt))
+        v[:, :3] = (self.acc.astype(np.float64) * hh + v[:, :3].astype(np.float64)).astype(np.float32)
+
     def sync(self):
         pass
 
@@ -75,7 +99,7 @@ class OracleKernels:
         return np.array([*(m[:, None] * v).sum(0), m.sum()])
 
 
-def run_rank(rank, world_size, port, exchange, n, split_len, steps, out_dir):
+def run_rank(rank, world_size, port, exchange, n, split_len, steps, out_dir, integrator="kick_drift"):
     import torch.distributed as dist
     from n_body_problem_amd import initial_conditions as ic
     from n_body_problem_amd.sharded import ShardedNBodySystem
@@ -83,7 +107,8 @@ def run_rank(rank, world_size, port, exchange, n, split_len, steps, out_dir):
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
     try:
         pos, vel = ic.plummer(n, seed=1234)
-        s = ShardedNBodySystem(n, exchange=exchange, kernels_factory=OracleKernels, split_len=split_len)
+        s = ShardedNBodySystem(n, exchange=exchange, kernels_factory=OracleKernels, split_len=split_len,
+                               integrator=integrator)
         s.setParticlesPosition(pos)
         s.setParticlesVelocity(vel)
         e0 = s.energy(1e-2)
@@ -91,7 +116,8 @@ def run_rank(rank, world_size, port, exchange, n, split_len, steps, out_dir):
         p, v = s.download()
         e1 = s.energy(1e-2)
         mom = s.momentum()
-        np.savez(os.path.join(out_dir, f"w{world_size}_{exchange}_r{rank}.npz"), p=p, v=v, e0=e0, e1=e1, mom=mom,
+        tag = exchange if integrator == "kick_drift" else exchange + "_" + integrator
+        np.savez(os.path.join(out_dir, f"w{world_size}_{tag}_r{rank}.npz"), p=p, v=v, e0=e0, e1=e1, mom=mom,
                  calls=np.array([c[1:] for c in s.kernels.calls if c[0] == "range"][-2:], dtype=np.int64),
                  kinds=np.array([c[0] for c in s.kernels.calls]), n_padded=s.n_padded, chunk=s.chunk)
         s.close()
@@ -100,7 +126,7 @@ def run_rank(rank, world_size, port, exchange, n, split_len, steps, out_dir):
             dist.destroy_process_group()
 
 
-def run_rank_gpu(rank, world_size, port, exchange, n, steps, out_dir):
+def run_rank_gpu(rank, world_size, port, exchange, n, steps, out_dir, integrator="kick_drift"):
     """One rank of a sharded run with the REAL HIP kernels; all ranks share cuda:0, gloo carries the exchange."""
     import torch
     import torch.distributed as dist
@@ -110,13 +136,14 @@ def run_rank_gpu(rank, world_size, port, exchange, n, steps, out_dir):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
     try:
         pos, vel = ic.plummer(n, seed=4321)
-        s = ShardedNBodySystem(n, device=0, exchange=exchange)
+        s = ShardedNBodySystem(n, device=0, exchange=exchange, integrator=integrator)
         s.setParticlesPosition(pos)
         s.setParticlesVelocity(vel)
         s.step_n(steps, 1e-3, 1e-3)
         p, v = s.download()
         e = s.energy(1e-3)
-        np.savez(os.path.join(out_dir, f"gpu_w{world_size}_{exchange}_r{rank}.npz"), p=p, v=v, e=e,
+        tag = exchange if integrator == "kick_drift" else exchange + "_" + integrator
+        np.savez(os.path.join(out_dir, f"gpu_w{world_size}_{tag}_r{rank}.npz"), p=p, v=v, e=e,
                  n_padded=s.n_padded, chunk=s.chunk, split_len=s.split_len)
         s.close()
     finally:

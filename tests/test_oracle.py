@@ -155,3 +155,24 @@ def test_golden_fixtures_reproduce(oracle_mod, golden_dir):
             p, v = oracle_mod.step_f32(g["pos0"], g["vel0"], dt, eps, nsteps=int(k), threads=1)
             assert np.array_equal(p, g[f"p32_{k}"]) and np.array_equal(v, g[f"v32_{k}"]), (f, k)
             assert rel_state_error(p, g[f"p64_{k}"]) < (1e-6 if k <= 10 else 1e-5)
+
+
+def test_kdk_is_second_order_and_time_reversible(oracle_mod):
+    """Velocity Verlet: energy error falls 4x when dt halves (kick-drift: 2x), and stepping
+    forward then backward returns to the start to rounding."""
+    from n_body_problem_amd import initial_conditions as ic
+    pos, vel = ic.plummer(512, seed=17)
+    e0 = oracle_mod.energy(pos, vel, 5e-2)[2]
+
+    def err(stepper, dt, nsteps):
+        p, v = stepper(pos, vel, dt, 5e-2, nsteps=nsteps)
+        return abs(oracle_mod.energy(p, v, 5e-2)[2] - e0) / abs(e0)
+
+    k1, k2 = err(oracle_mod.step_kdk_f32, 2e-2, 50), err(oracle_mod.step_kdk_f32, 1e-2, 100)
+    d1, d2 = err(oracle_mod.step_f32, 2e-2, 50), err(oracle_mod.step_f32, 1e-2, 100)
+    assert k1 < d1 and k2 < d2                      # better than kick-drift at the same dt
+    assert 2.5 < k1 / k2 < 6.0                      # ~ dt^2
+    p, v = oracle_mod.step_kdk_f32(pos, vel, 1e-2, 5e-2, nsteps=20)
+    v[:, :3] *= -1
+    p, v = oracle_mod.step_kdk_f32(p, v, 1e-2, 5e-2, nsteps=20)
+    assert rel_state_error(p, pos) < 1e-5

@@ -361,3 +361,32 @@ def test_symmetric_mode_zero_softening_and_limits(nb):
     with nb.NBodySystem(32768, row_lo=0, row_count=16384) as s:
         with pytest.raises(nb.NBodyError):
             s.set_force_mode("symmetric")
+
+
+# ---- N4: kick-drift-kick integrator ----------------------------------------------------------------------------
+
+def test_kdk_matches_oracle_and_conserves_energy_better(nb, oracle_mod):
+    pos, vel = nb.plummer(4096, seed=44)
+    with nb.NBodySystem(4096) as s:
+        s.set_integrator("kdk")
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        e0 = s.energy(2e-2)
+        s.step_n(20, 1e-2, 2e-2)
+        p, v = s.download()
+        e_kdk = s.energy(2e-2)
+    pr, vr = oracle_mod.step_kdk_f32(pos, vel, 1e-2, 2e-2, nsteps=20)
+    assert rel_state_error(p, pr) < TOL and rel_state_error(v, vr) < TOL
+    with nb.NBodySystem(4096) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(20, 1e-2, 2e-2)
+        e_kd = s.energy(2e-2)
+    assert abs(e_kdk[2] - e0[2]) < abs(e_kd[2] - e0[2])
+    with nb.NBodySystem(4096) as s:                       # the pieces need their prerequisites
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        with pytest.raises(nb.NBodyError):
+            s.kdk_kick_drift(1e-2)
+        with pytest.raises(nb.NBodyError):
+            s.kdk_kick(1e-2)

@@ -60,3 +60,21 @@ def test_two_ranks_on_one_gpu_reproduce_one_context_bit_for_bit(tmp_path, exchan
         assert int(g["split_len"]) == nb.default_split_len(n)
         assert np.array_equal(g["p"], p) and np.array_equal(g["v"], v), (exchange, r)
         assert np.allclose(g["e"], e, rtol=1e-9)
+
+
+def test_two_ranks_kdk_on_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    import n_body_problem_amd as nb
+    n, steps = 40000, 3
+    pos, vel = nb.plummer(n, seed=4321)
+    with nb.NBodySystem(n) as s:
+        s.set_integrator("kdk")
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(steps, 1e-3, 1e-3)
+        p, v = s.download()
+    out = str(tmp_path)
+    mp.spawn(run_rank_gpu, args=(2, free_port(), "allgather", n, steps, out, "kdk"), nprocs=2, join=True)
+    for r in range(2):
+        g = np.load(os.path.join(out, f"gpu_w2_allgather_kdk_r{r}.npz"))
+        assert np.array_equal(g["p"], p) and np.array_equal(g["v"], v), r
