@@ -58,6 +58,30 @@ def cpu_baseline(pos, softening, target_seconds):
                       f"oracle/nbody_oracle.c reference-order fp32 (extrapolates linearly in rows)"}
 
 
+def reference_size_leg(nb):
+    """The only timing the reference publishes: "1.6 ms" per step for its final VERSION 3 on an RTX 4090
+    (kernel.cu:73), most plausibly at galaxy_20K's N = 20000 padded to 20225.  The same
+    size here, with the reference's dt and effective softening; side information, not the headline metric."""
+    import torch
+    n = 20000
+    pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[1])
+    ppos, pvel = nb.pad_reference_style(pos, vel)            # the reference's 20225-body buffers
+    s = nb.NBodySystem(ppos.shape[0])
+    s.setParticlesPosition(ppos)
+    s.setParticlesVelocity(pvel)
+    s.step_n(20, nb.TIME_TICK, nb.SOFTENING_VERSION3)
+    torch.cuda.synchronize()
+    k = 200
+    t0 = time.perf_counter()
+    s.step_n(k, nb.TIME_TICK, nb.SOFTENING_VERSION3)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / k
+    s.close()
+    return {"n_bodies": n, "n_padded": int(ppos.shape[0]), "ms_per_step": ms, "interactions_per_s": float(n) * n / (ms * 1e-3),
+            "reference_ms_per_step": 1.6, "reference_hardware": "RTX 4090 (source comment kernel.cu:73, N inferred)",
+            "speedup_vs_reference_comment": 1.6 / ms}
+
+
 def pair_once_leg(nb, n, pos, vel, args):
     """The experimental pair-once kernel on the same state, reported BESIDE the headline, never as
     it: N^2/t for comparison, and the roofline fraction from the pair evaluations it actually executes."""
@@ -239,6 +263,8 @@ def main():
         }
         if world == 1 and args.force_mode == "one_sided" and not args.no_pair_once:
             out["pair_once"] = pair_once_leg(nb, n, pos, vel, args)
+        if world == 1 and args.force_mode == "one_sided" and not args.no_pair_once:
+            out["reference_size"] = reference_size_leg(nb)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, args.softening, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -54,8 +54,8 @@ const char *nbody_status_string(int status);
  * nbody_create      : all n_total bodies are rows and columns of this context (one GPU).
  * nbody_create_shard: the context integrates rows [row_lo, row_lo+row_count) against all n_total
  *                     columns (one rank of a multi-GPU run).  split_len = columns per partial sum,
- *                     a multiple of 256, 0 = nbody_default_split_len(n_total) (8192 columns for
- *                     131072 <= n_total <= 1048576, else n_total/16 or n_total/128); row_lo must be a
+ *                     a multiple of 256, 0 = nbody_default_split_len(n_total) (n_total/128 rounded up to
+ *                     a multiple of 256, at most 8192); row_lo must be a
  *                     multiple of split_len so that shard boundaries never cut a split.
  * The context owns the acceleration partials (the reference's gravity_sum_array), a stream and, on
  * demand, position/velocity buffers.  n_total need not be padded; the reference's roundup(n,256)+1

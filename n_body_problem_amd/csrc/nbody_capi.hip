@@ -81,20 +81,16 @@ const char *nbody_last_error(const nbody_ctx *ctx) { return ctx ? ctx->err.c_str
 int64_t nbody_default_split_len(int64_t n_total)
 {
     // Columns per partial sum.  A function of n_total ONLY: split boundaries define the summation order, so
-    // they must not depend on the sharding.  8192 columns (32 LDS tiles) per split while that gives 16..128
-    // splits; outside that range the split count is pinned to 16 (small N) or 128 (large N).  Many splits
-    // keep the grid fine-grained when 8 ranks share N = 2^20 (each rank: 64 row tiles x 128 splits).
+    // they must not depend on the sharding.  n_total/128 rounded up to whole 256-body tiles, at most 8192
+    // (32 LDS tiles): 128 splits up to 2^20 bodies (79 at the reference's 20 000), n_total/8192 beyond.
+    // Many short splits keep the grid fine-grained -- at N = 65 536 a 256-column split measured 20 % faster
+    // than a 4096-column one, and 8 ranks sharing N = 2^20 still get 128 row tiles x 128 splits each -- at
+    // the price of 16 B x n_splits per row of partial sums (2 GiB at N = 2^20, ~0.4 % of the step time).
     if (n_total <= 0)
         return kTile;
-    const int64_t target = 8192;
-    int64_t len;
-    if (n_total < 16 * target)
-        len = (n_total + 15) / 16;
-    else if (n_total <= 128 * target)
-        len = target;
-    else
-        len = (n_total + 127) / 128;
-    return (len + kTile - 1) / kTile * kTile;
+    int64_t len = (n_total + 127) / 128;
+    len = (len + kTile - 1) / kTile * kTile;
+    return len > 8192 ? 8192 : len;
 }
 
 int64_t nbody_split_len(const nbody_ctx *ctx) { return ctx ? ctx->split_len : 0; }

@@ -46,9 +46,9 @@ def test_default_split_len_is_tile_aligned_and_sharding_independent(lib):
     for n in (1, 255, 256, 257, 1024, 20000, 65536, 1 << 20, (1 << 22) + 1):
         s = lib.nbody_default_split_len(n)
         assert s % 256 == 0 and s >= 256
-        assert (n + s - 1) // s <= 128
-    assert lib.nbody_default_split_len(1 << 20) == 8192 and lib.nbody_default_split_len(1 << 22) == 32768
-    assert lib.nbody_default_split_len(65536) == 4096 and lib.nbody_default_split_len(1000) == 256
+        assert s <= 8192 and (n + s - 1) // s <= max(128, (n + 8191) // 8192)
+    assert lib.nbody_default_split_len(1 << 20) == 8192 and lib.nbody_default_split_len(1 << 22) == 8192
+    assert lib.nbody_default_split_len(65536) == 512 and lib.nbody_default_split_len(20000) == 256
 
 
 def test_argument_errors_come_before_any_device_work(lib):

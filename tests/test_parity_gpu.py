@@ -329,7 +329,7 @@ def sym_run(nb, pos, vel, dt, eps, steps, mode, split_len=0):
         return s.download()
 
 
-@pytest.mark.parametrize("n,split_len", [(16384, 0), (20000, 0), (5000, 1024), (65536, 0)])
+@pytest.mark.parametrize("n,split_len", [(16384, 1024), (20000, 1280), (5000, 1024), (65536, 4096), (262144, 0)])
 def test_symmetric_mode_matches_oracle_and_one_sided(nb, oracle_mod, n, split_len):
     pos, vel = nb.uniform_cube(n, seed=200 + n, random_masses=True, speed=0.2) if n < 30000 else nb.plummer(n, seed=n)
     zero = np.zeros_like(vel)
@@ -352,8 +352,8 @@ def test_symmetric_mode_matches_oracle_and_one_sided(nb, oracle_mod, n, split_le
 def test_symmetric_mode_zero_softening_and_limits(nb):
     pos, vel = nb.uniform_cube(16384, seed=9, random_masses=True)
     pos[5] = pos[6]                                   # two coincident bodies
-    a = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "symmetric")[1][:, :3]
-    b = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "one_sided")[1][:, :3]
+    a = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "symmetric", 1024)[1][:, :3]
+    b = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "one_sided", 1024)[1][:, :3]
     assert np.all(np.isfinite(a)) and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
     with nb.NBodySystem(4096) as s:                   # split_len = 256 < 1024
         with pytest.raises(nb.NBodyError):
