@@ -9,8 +9,8 @@ rows of the interaction matrix are independent given all positions:
   with the force kernel on the rank's OWN column chunk, which needs no remote data; only then does the
   compute stream wait for remote chunks.
 
-``exchange="allgather"``: one in-place RCCL all-gather per step (RCCL runs it as a ring over xGMI), issued
-right after the update kernel; the next step's own-chunk force kernel runs beside it.
+``exchange="allgather"``: one RCCL all-gather per step (RCCL runs it as a ring over xGMI), issued right after
+the update kernel; the next step's own-chunk force kernel runs beside it.
 ``exchange="ring"``: the ring spelled out as P-1 send/recv hops on a communication stream; the force
 kernel of chunk (r-h) starts as soon as hop h has landed, while later hops are still on the wire.
 
@@ -84,8 +84,13 @@ class ShardedNBodySystem:
         self.velocities = self.kernels.velocities    # own rows, (chunk, 4)
         self._on_gpu = bool(self.positions.is_cuda)
         backend = dist.get_backend(group) if self.distributed else "none"
-        # RCCL gathers in place; other backends (gloo in the tests) get a staging copy of the own chunk
-        self._inplace = self._on_gpu and backend == "nccl"
+        self._rccl = self._on_gpu and backend == "nccl"
+        # The all-gather sends a staged copy of the own chunk (2 MiB at N = 2^20, P = 8: one ~3 us copy per step)
+        # and receives into the replica; RCCL then rewrites the own chunk with the bytes it already holds while the
+        # next step's own-chunk kernel may be reading them, which is harmless.  NBODY_ALLGATHER_INPLACE=1 gathers
+        # in place instead (sendbuff == recvbuff + rank*count, no self copy).
+        import os
+        self._inplace = self._rccl and os.environ.get("NBODY_ALLGATHER_INPLACE", "0") == "1"
         self._send = None if self._inplace else torch.empty_like(self.positions[:self.chunk])
         self._comm_stream = torch.cuda.Stream(device=self.positions.device) if self._on_gpu else None
         self._side_stream = torch.cuda.Stream(device=self.positions.device) if self._on_gpu else None
@@ -138,8 +143,6 @@ class ShardedNBodySystem:
     def _start_allgather(self) -> None:
         dist = self._dist
         if self._inplace:
-            # in place: RCCL recognises sendbuff == recvbuff + rank*count and skips the self copy, so the
-            # own chunk is never written while the next step's own-chunk force kernel reads it
             send = self._chunk(self.rank)
         else:
             self._send.copy_(self._chunk(self.rank))
@@ -155,7 +158,7 @@ class ShardedNBodySystem:
         On return the CURRENT stream is ordered after the arrival; the hop itself runs on the comm stream."""
         torch, dist = self._torch, self._dist
         nxt, prv = self._peer(self.rank + 1), self._peer(self.rank - 1)
-        if self._inplace:  # RCCL: device buffers, ordered on the communication stream
+        if self._rccl:  # RCCL: device buffers, ordered on the communication stream
             ops = [dist.P2POp(dist.isend, self._chunk(send_c), nxt, group=self.group),
                    dist.P2POp(dist.irecv, self._chunk(recv_c), prv, group=self.group)]
             with torch.cuda.stream(self._comm_stream):
