@@ -20,7 +20,7 @@ static void usage()
 {
     std::cerr << "usage: nbody_run [dataset_id 0-5] [--data-dir DIR] [--file PATH] [--plummer N] [--seed S] [--resume SNAPSHOT]\n"
                  "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P]\n"
-                 "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once]\n";
+                 "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once] [--particle-softening]\n";
 }
 
 int main(int argc, char **argv)
@@ -30,7 +30,7 @@ int main(int argc, char **argv)
     std::int64_t plummer_n = 0, steps = 100, energy_every = 0, dump_every = 0;
     std::uint64_t seed = 0x5EED0003ull;
     float dt = nbody::kTimeTick, softening = nbody::kSofteningVersion3;  // the reference's constants
-    bool pad = false, kdk = false, pair_once = false;
+    bool pad = false, kdk = false, pair_once = false, particle_eps = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
@@ -49,6 +49,7 @@ int main(int argc, char **argv)
         else if (a == "--pad-reference") pad = true;
         else if (a == "--kdk") kdk = true;
         else if (a == "--pair-once") pair_once = true;
+        else if (a == "--particle-softening") particle_eps = true;
         else if (a == "--device") device = std::atoi(next().c_str());
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-') {
@@ -74,6 +75,11 @@ int main(int argc, char **argv)
         sys.timing(true);
         if (kdk) sys.setKickDriftKick(true);       // velocity Verlet instead of the reference's kick-drift
         if (pair_once) sys.setPairOnce(true);      // the experimental pair-once force kernel
+        if (particle_eps) {                        // the eps column of the velocity records (kernel.cu:223, 237), unused there
+            std::vector<float> eps((size_t)b.n());
+            for (std::int64_t i = 0; i < b.n(); ++i) eps[(size_t)i] = b.vel[4 * (size_t)i + 3];
+            sys.setParticleSoftening(eps.data());
+        }
         nbody::System::Energy e0{};
         if (energy_every > 0) {
             e0 = sys.energy(softening);

@@ -157,6 +157,14 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 
+/* Per-particle softening: the reference loads a per-particle eps into velocities[4i+3]
+ * (kernel.cu:223, 237) and no kernel ever reads it.  With d_eps (n_total floats on the device, borrowed until replaced;
+ * NULL switches it off) every pair is softened by eps_ij^2 = softening^2 + eps_i^2 + eps_j^2 in the forces and in
+ * nbody_energy.  One extra add per interaction, compiler-allocated kernel only; not available in the pair-once mode. */
+int nbody_set_particle_softening(nbody_ctx *ctx, const float *d_eps);
+/* The same from n_total HOST floats, copied into a buffer the context owns (NULL switches it off). */
+int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);
+
 /* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default = 4, the kernel
  * with the hand-allocated inner loop; -4 = four rows with the compiler-allocated loop).  Never changes a result bit. */
 int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);

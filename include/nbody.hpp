@@ -76,6 +76,13 @@ public:
         check(nbody_set_force_mode(ctx_, on ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED), "nbody_set_force_mode");
     }
 
+    // per-particle softening lengths of all numBodies bodies (host floats, e.g. velocities[4i+3] of the reference's
+    // loaders, kernel.cu:223); nullptr switches it off.  eps_ij^2 = softening^2 + eps_i^2 + eps_j^2.
+    void setParticleSoftening(const float *hostEps)
+    {
+        check(nbody_upload_particle_softening(ctx_, hostEps), "nbody_upload_particle_softening");
+    }
+
     struct Energy { double kinetic, potential, total; };
     Energy energy(float softening)
     {

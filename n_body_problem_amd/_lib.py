@@ -62,6 +62,8 @@ _PROTOTYPES = {
     "nbody_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
                                   POINTER(c_int64)]),
     "nbody_set_force_mode": (c_int, [c_void_p, c_int]),
+    "nbody_set_particle_softening": (c_int, [c_void_p, c_void_p]),
+    "nbody_upload_particle_softening": (c_int, [c_void_p, c_void_p]),
     "nbody_set_rows_per_lane": (c_int, [c_void_p, c_int]),
     "nbody_device_info": (c_int, [c_void_p, POINTER(c_int64), c_char_p, c_int]),
 }

@@ -21,6 +21,8 @@ struct nbody_ctx {
     int integrator = NBODY_INTEGRATOR_KICK_DRIFT;
     float4 *acc = nullptr;      // kick-drift-kick mode: accelerations of the own rows at the current positions
     bool acc_valid = false;
+    const float *eps_pp = nullptr;  // per-particle softening lengths in use, n_total floats (borrowed or eps_own), or NULL
+    float *eps_own = nullptr;       // the copy nbody_upload_particle_softening made
     int2 *sym_tiles = nullptr;  // pair-once mode: the (I <= J) split pairs, one workgroup each
     int sym_n_tiles = 0;
     int cu_count = 256;
@@ -181,6 +183,7 @@ int nbody_destroy(nbody_ctx *c)
     if (c->partials) (void)hipFree(c->partials);
     if (c->pos) (void)hipFree(c->pos);
     if (c->vel) (void)hipFree(c->vel);
+    if (c->eps_own) (void)hipFree(c->eps_own);
     if (c->reduce_dev) (void)hipFree(c->reduce_dev);
     if (c->sym_tiles) (void)hipFree(c->sym_tiles);
     if (c->acc) (void)hipFree(c->acc);
@@ -370,6 +373,31 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
     return NBODY_OK;
 }
 
+int nbody_set_particle_softening(nbody_ctx *c, const float *d_eps)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    c->eps_pp = d_eps;
+    c->acc_valid = false;
+    return NBODY_OK;
+}
+
+int nbody_upload_particle_softening(nbody_ctx *c, const float *h_eps)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    if (!h_eps)
+        return nbody_set_particle_softening(c, nullptr);
+    if (c->n_total == 0)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->eps_own && hipMalloc(&c->eps_own, sizeof(float) * (size_t)c->n_total) != hipSuccess)
+        return fail(c, NBODY_ERR_ALLOC, "nbody_upload_particle_softening: hipMalloc failed");
+    HIP_TRY(c, hipMemcpyAsync(c->eps_own, h_eps, sizeof(float) * (size_t)c->n_total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return nbody_set_particle_softening(c, c->eps_own);
+}
+
 int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
 {
     if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == -4 || rpl == 8))
@@ -407,6 +435,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
     if (c->row_count == 0 || c->n_total == 0)
         return NBODY_OK;
     if (c->force_mode == NBODY_FORCE_SYMMETRIC) {
+        if (c->eps_pp)
+            return fail(c, NBODY_ERR_INVALID, std::string(who) + ": the pair-once mode has no per-particle softening");
         if (complement || col_lo != 0 || col_lo + col_count != c->n_total)
             return fail(c, NBODY_ERR_INVALID, std::string(who) + ": the pair-once mode computes all columns in one call");
         SymArgs sa;
@@ -435,6 +465,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
     a.n_total = (int)c->n_total;
     a.split_len = (int)c->split_len;
     a.eps2 = softening * softening;
+    a.eps_pp = c->eps_pp;
     if (complement) {  // every split except [first, first+count)
         a.split_first = 0;
         a.split_count = c->n_splits - count;
@@ -679,7 +710,7 @@ int nbody_energy(nbody_ctx *c, const float *d_pos, const float *d_vel, float sof
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_energy(reinterpret_cast<const float4 *>(d_pos), reinterpret_cast<const float4 *>(d_vel),
                              c->reduce_dev, (int)c->row_lo, (int)c->row_count, (int)c->n_total,
-                             softening * softening, c->stream));
+                             softening * softening, c->eps_pp, c->stream));
     double ku[2];
     int rc = reduce_blocks(c, 2, ku);
     if (rc != NBODY_OK)

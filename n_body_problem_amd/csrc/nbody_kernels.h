@@ -20,6 +20,7 @@ struct ForceArgs {
     int skip_first;      // splits [skip_first, skip_first+skip_count) are stepped over (a launch that covers
     int skip_count;      //   "every split except a range": split = split_first + y, += skip_count once >= skip_first
     float eps2;          // softening length squared
+    const float *eps_pp; // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
 };
 
 // EXPERIMENTAL pair-once kernel (nbody_symmetric.hip): one workgroup per pair of splits (I <= J).
@@ -59,7 +60,7 @@ hipError_t launch_scatter_mass(float4 *pos_all, const float *masses, int n_total
 
 // Per-block {kinetic, potential} doubles into block_out[2*gridDim.x]; returns the grid size used.
 hipError_t launch_energy(const float4 *pos_all, const float4 *vel_rows, double *block_out, int row_lo,
-                         int row_count, int n_total, float eps2, hipStream_t stream);
+                         int row_count, int n_total, float eps2, const float *eps_pp, hipStream_t stream);
 int energy_blocks(int row_count);
 
 // Per-block {px,py,pz,m} doubles into block_out[4*gridDim.x].

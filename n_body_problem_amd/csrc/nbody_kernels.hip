@@ -32,10 +32,13 @@ template <> __device__ __forceinline__ void idle_gap<1>() { asm volatile("s_nop 
 // (row = tile_base + k*kTile + lane-in-block, so row loads/stores are coalesced float4) and walks the
 // split's columns in ascending order, one fp32 FMA chain per row: the order bit-exactly defines the
 // partial sum whatever the grid, RPL or sharding.
-template <int RPL, bool GUARD>
+// PPS: per-particle softening (the eps the reference loads into vel.w, kernel.cu:223, and never uses):
+// eps_ij^2 = eps^2 + eps_i^2 + eps_j^2, one extra add per interaction and a second, scalar LDS tile.
+template <int RPL, bool GUARD, bool PPS = false>
 __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 {
     __shared__ float4 tile[2][kTile];
+    __shared__ float etile[PPS ? 2 : 1][PPS ? kTile : 1];
 
     const int tid = threadIdx.x;
     int split = a.split_first + blockIdx.y;
@@ -46,16 +49,21 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     const int ntiles = (j1 - j0 + kTile - 1) / kTile;
     const int row_base = blockIdx.x * (kTile * RPL) + tid;
 
-    float xi[RPL], yi[RPL], zi[RPL], ax[RPL], ay[RPL], az[RPL];
+    float xi[RPL], yi[RPL], zi[RPL], ax[RPL], ay[RPL], az[RPL], ei2[RPL];
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const int r = row_base + k * kTile;
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < a.row_count)
+        float e = 0.f;
+        if (r < a.row_count) {
             p = a.pos[a.row_lo + r];
+            if (PPS)
+                e = a.eps_pp[a.row_lo + r];
+        }
         xi[k] = p.x;
         yi[k] = p.y;
         zi[k] = p.z;
+        ei2[k] = __builtin_fmaf(e, e, a.eps2);  // eps^2 + eps_i^2
         ax[k] = ay[k] = az[k] = 0.f;
     }
     float eps2;  // kept in a VGPR: an SGPR source costs an fp32 instruction two extra cycles on gfx950
@@ -63,20 +71,31 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 
     // an out-of-range column is staged as a zero-mass body at the origin: it adds exactly 0
     float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j0 + tid < j1)
+    float stage_e = 0.f;
+    if (j0 + tid < j1) {
         stage = a.pos[j0 + tid];
+        if (PPS)
+            stage_e = a.eps_pp[j0 + tid];
+    }
     tile[0][tid] = stage;
+    if (PPS)
+        etile[0][tid] = stage_e * stage_e;
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int jn = j0 + (t + 1) * kTile + tid;
         if (t + 1 < ntiles) {  // in flight under the tile's arithmetic
             stage = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (jn < j1)
+            stage_e = 0.f;
+            if (jn < j1) {
                 stage = a.pos[jn];
+                if (PPS)
+                    stage_e = a.eps_pp[jn];
+            }
         }
 
         const float4 *cur = tile[t & 1];
+        const float *ecur = etile[PPS ? (t & 1) : 0];
         float4 pj = cur[0];  // wave-uniform address: broadcast ds_read_b128
 #pragma unroll 4
         for (int jj = 0; jj < kTile; ++jj) {
@@ -86,7 +105,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
                 dx[k] = pj.x - xi[k];
                 dy[k] = pj.y - yi[k];
                 dz[k] = pj.z - zi[k];
-                float r2 = __builtin_fmaf(dx[k], dx[k], eps2);
+                float r2 = __builtin_fmaf(dx[k], dx[k], PPS ? ei2[k] + ecur[jj] : eps2);
                 r2 = __builtin_fmaf(dy[k], dy[k], r2);
                 r2 = __builtin_fmaf(dz[k], dz[k], r2);
                 if (GUARD)  // eps == 0: a pair at zero distance (the self pair) must contribute 0, not NaN
@@ -114,8 +133,11 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
             pj = pn;
         }
 
-        if (t + 1 < ntiles)
+        if (t + 1 < ntiles) {
             tile[(t + 1) & 1][tid] = stage;
+            if (PPS)
+                etile[(t + 1) & 1][tid] = stage_e * stage_e;
+        }
         __syncthreads();
     }
 
@@ -262,6 +284,13 @@ static hipError_t launch_forces_rpl(const ForceArgs &a, hipStream_t stream)
 {
     const int rows_per_block = kTile * RPL;
     dim3 grid((a.row_count + rows_per_block - 1) / rows_per_block, a.split_count, 1);
+    if (a.eps_pp) {  // per-particle softening: a particle may have eps = 0, so the guard stays on when eps = 0
+        if (a.eps2 > 0.f)
+            hipLaunchKernelGGL((force_kernel<RPL, false, true>), grid, dim3(kTile), 0, stream, a);
+        else
+            hipLaunchKernelGGL((force_kernel<RPL, true, true>), grid, dim3(kTile), 0, stream, a);
+        return hipGetLastError();
+    }
     if (a.eps2 > 0.f)
         hipLaunchKernelGGL((force_kernel<RPL, false>), grid, dim3(kTile), 0, stream, a);
     else
@@ -287,7 +316,7 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
     switch (rows_per_lane) {
     case 1: return launch_forces_rpl<1>(a, stream);
     case 2: return launch_forces_rpl<2>(a, stream);
-    case 4: return launch_forces_r4_asm(a, stream);
+    case 4: return a.eps_pp ? launch_forces_rpl<4>(a, stream) : launch_forces_r4_asm(a, stream);
     case -4: return launch_forces_rpl<4>(a, stream);
     case 8: return launch_forces_rpl<8>(a, stream);
     default: return hipErrorInvalidValue;
@@ -452,32 +481,44 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *bloc
 
 // Potential of each row against ALL columns (self pair excluded by index), fp32 pair terms, fp32 sum
 // inside a tile, fp64 across tiles and across rows; kinetic energy of the rows.
+template <bool PPS>
 __global__ __launch_bounds__(kTile) void energy_kernel(const float4 *pos_all, const float4 *vel_rows,
                                                        double *block_out, int row_lo, int row_count, int n_total,
-                                                       float eps2)
+                                                       float eps2, const float *eps_pp)
 {
     __shared__ float4 tile[kTile];
+    __shared__ float etile[PPS ? kTile : 1];
     const int tid = threadIdx.x;
     const int r = blockIdx.x * kTile + tid;
     const bool live = r < row_count;
     const int gi = row_lo + r;
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live)
+    float ei2 = eps2;
+    if (live) {
         pi = pos_all[gi];
+        if (PPS)
+            ei2 = __builtin_fmaf(eps_pp[gi], eps_pp[gi], eps2);
+    }
     double phi = 0.0;
     for (int j0 = 0; j0 < n_total; j0 += kTile) {
         __syncthreads();
         float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j0 + tid < n_total)
+        float et = 0.f;
+        if (j0 + tid < n_total) {
             pt = pos_all[j0 + tid];
+            if (PPS)
+                et = eps_pp[j0 + tid];
+        }
         tile[tid] = pt;
+        if (PPS)
+            etile[tid] = et * et;
         __syncthreads();
         float s = 0.f;
 #pragma unroll 8
         for (int jj = 0; jj < kTile; ++jj) {
             const float4 pj = tile[jj];
             const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, PPS ? ei2 + etile[jj] : eps2)));
             const float inv = (j0 + jj != gi && r2 > 0.f) ? __builtin_amdgcn_rsqf(r2) : 0.f;
             s = __builtin_fmaf(pj.w, inv, s);
         }
@@ -495,12 +536,16 @@ __global__ __launch_bounds__(kTile) void energy_kernel(const float4 *pos_all, co
 int energy_blocks(int row_count) { return (row_count + kTile - 1) / kTile; }
 
 hipError_t launch_energy(const float4 *pos_all, const float4 *vel_rows, double *block_out, int row_lo,
-                         int row_count, int n_total, float eps2, hipStream_t stream)
+                         int row_count, int n_total, float eps2, const float *eps_pp, hipStream_t stream)
 {
     if (row_count <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(energy_kernel, dim3(energy_blocks(row_count)), dim3(kTile), 0, stream, pos_all, vel_rows,
-                       block_out, row_lo, row_count, n_total, eps2);
+    if (eps_pp)
+        hipLaunchKernelGGL(energy_kernel<true>, dim3(energy_blocks(row_count)), dim3(kTile), 0, stream, pos_all, vel_rows,
+                           block_out, row_lo, row_count, n_total, eps2, eps_pp);
+    else
+        hipLaunchKernelGGL(energy_kernel<false>, dim3(energy_blocks(row_count)), dim3(kTile), 0, stream, pos_all, vel_rows,
+                           block_out, row_lo, row_count, n_total, eps2, eps_pp);
     return hipGetLastError();
 }
 

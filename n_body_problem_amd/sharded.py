@@ -118,6 +118,20 @@ class ShardedNBodySystem:
     set_particles_position = setParticlesPosition
     set_particles_velocity = setParticlesVelocity
 
+    def set_particle_softening(self, eps) -> None:
+        """Per-particle softening lengths of ALL ``num_bodies`` bodies, the same on every rank (the columns need every
+        body's length; it is static, so there is nothing to exchange per step).  ``None`` switches it off."""
+        if eps is None:
+            self.kernels.set_particle_softening(None)
+        else:
+            e = np.ascontiguousarray(eps, dtype=np.float32).reshape(-1)
+            if e.shape[0] != self.num_bodies:
+                raise ValueError(f"expected {self.num_bodies} softening lengths, got {e.shape[0]}")
+            padded = np.zeros(self.n_padded, dtype=np.float32)
+            padded[:self.num_bodies] = e
+            self.kernels.set_particle_softening(padded)
+        self._kdk_ready = False
+
     def download(self):
         """Full (positions, velocities) of the real bodies on every rank (velocities are gathered)."""
         torch, dist = self._torch, self._dist

@@ -65,6 +65,7 @@ class NBodySystem:
                                            int(split_len)), None)
         self._ctx = ctx
         self.split_len = int(self._lib.nbody_split_len(ctx))
+        self._eps_pp = None
         # the reference's two device buffers: position "VBO" (all bodies) and velocities (own rows)
         self.positions = torch.zeros((self.num_bodies, 4), dtype=torch.float32, device=self.device)
         self.velocities = torch.zeros((self.row_count, 4), dtype=torch.float32, device=self.device)
@@ -218,6 +219,20 @@ class NBodySystem:
         """``"one_sided"`` (default) or ``"symmetric"`` (experimental pair-once kernel, single context only)."""
         code = {"one_sided": 0, "symmetric": 1}[mode]
         check(self._lib.nbody_set_force_mode(self._ctx, code), self._ctx)
+
+    def set_particle_softening(self, eps) -> None:
+        """Per-particle softening lengths for ALL bodies (host array or device tensor of ``num_bodies`` floats), e.g.
+        the ``vel[:,3]`` the reference's loaders fill; ``None`` switches it off.  eps_ij^2 = softening^2 + eps_i^2 + eps_j^2."""
+        torch = _torch()
+        if eps is None:
+            self._eps_pp = None
+        else:
+            t = eps if torch.is_tensor(eps) else torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32))
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            if t.numel() != self.num_bodies:
+                raise ValueError(f"expected {self.num_bodies} softening lengths, got {t.numel()}")
+            self._eps_pp = t  # keeps the borrowed device buffer alive
+        check(self._lib.nbody_set_particle_softening(self._ctx, _ptr(self._eps_pp)), self._ctx)
 
     def set_rows_per_lane(self, rpl: int) -> None:
         check(self._lib.nbody_set_rows_per_lane(self._ctx, int(rpl)), self._ctx)

@@ -45,6 +45,10 @@ def lib() -> ctypes.CDLL:
         L.oracle_accel_f64_from_f32.argtypes = [_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
                                                 _f64p, _c_int]
         L.oracle_accel_f64_from_f32.restype = _c_int
+        L.oracle_accel_f64_pps.argtypes = [_f64p, _f64p, _c_int, _c_int, _c_int, ctypes.c_double, _f64p]
+        L.oracle_accel_f64_pps.restype = None
+        L.oracle_potential_pps.argtypes = [_f64p, _f64p, _c_int, ctypes.c_double]
+        L.oracle_potential_pps.restype = ctypes.c_double
         L.oracle_update_f32.argtypes = [_f32p, _f32p, _f32p, _c_int, _c_int, ctypes.c_float]
         L.oracle_update_f32.restype = None
         L.oracle_step_f32.argtypes = [_f32p, _f32p, _c_int, ctypes.c_float, ctypes.c_float, _c_int, _c_int]
@@ -103,6 +107,23 @@ def accel_f64(pos, i0=0, i1=None, j0=0, j1=None, eps=1e-3, threads=None) -> np.n
     if i1 > i0:
         lib().oracle_accel_f64(p, i0, i1, j0, j1, float(eps), out, threads or host_threads())
     return out
+
+
+def accel_f64_pps(pos, eps_pp, eps=0.0, i0=0, i1=None) -> np.ndarray:
+    """fp64 accelerations with per-particle softening: eps_ij^2 = eps^2 + eps_i^2 + eps_j^2."""
+    p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 4)
+    e = np.ascontiguousarray(eps_pp, dtype=np.float64).reshape(-1)
+    n = p.shape[0]
+    i1 = n if i1 is None else i1
+    out = np.zeros((i1 - i0, 3), dtype=np.float64)
+    lib().oracle_accel_f64_pps(p, e, n, i0, i1, float(eps), out)
+    return out
+
+
+def potential_pps(pos, eps_pp, eps=0.0) -> float:
+    p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 4)
+    e = np.ascontiguousarray(eps_pp, dtype=np.float64).reshape(-1)
+    return float(lib().oracle_potential_pps(p, e, p.shape[0], float(eps)))
 
 
 def step_f32(pos, vel, dt, eps, nsteps=1, threads=None):

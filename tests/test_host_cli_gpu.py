@@ -61,3 +61,28 @@ def test_cli_reads_the_reference_formats(tmp_path):
         want_p, want_v = s.download()
     err = np.abs(p[:300, :3] - want_p[:, :3]).max() / np.abs(want_p[:, :3]).max()
     assert err < 1e-6 and np.array_equal(v[:300, 3], vel[:, 3])
+
+
+def test_cli_particle_softening_from_the_velocity_records(tmp_path):
+    """--particle-softening uses the eps column the reference's loaders fill (kernel.cu:223) as per-particle lengths."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd import datasets as ds
+    pos, vel = nb.plummer(3000, seed=92)
+    vel[:, 3] = np.random.default_rng(92).uniform(0.0, 0.05, 3000).astype(np.float32)
+    start = str(tmp_path / "start.nbs")
+    ds.save_snapshot(start, pos, vel, step=0, time=0.0)
+    run_cli("--resume", start, "--steps", 3, "--dt", 1e-3, "--softening", 1e-3, "--particle-softening", "--final",
+            tmp_path / "out.nbs")
+    p, v, _, _ = ds.load_snapshot(str(tmp_path / "out.nbs"))
+    with nb.NBodySystem(3000) as s:
+        s.set_particle_softening(vel[:, 3])
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(3, 1e-3, 1e-3)
+        want_p, want_v = s.download()
+    assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
+    with nb.NBodySystem(3000) as s:   # and it is not the plain run
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(3, 1e-3, 1e-3)
+        assert not np.array_equal(s.download()[1], want_v)

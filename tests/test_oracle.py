@@ -176,3 +176,21 @@ def test_kdk_is_second_order_and_time_reversible(oracle_mod):
     v[:, :3] *= -1
     p, v = oracle_mod.step_kdk_f32(p, v, 1e-2, 5e-2, nsteps=20)
     assert rel_state_error(p, pos) < 1e-5
+
+
+def test_per_particle_softening_oracle_known_answers(oracle_mod):
+    """eps_ij^2 = eps^2 + eps_i^2 + eps_j^2: two unit masses at distance 1 with lengths 0.3 and 0.4 and eps = 0 feel
+    1/(1 + 0.25)^1.5; equal lengths e are a global softening of sqrt(eps^2 + 2 e^2)."""
+    pos = np.array([[0, 0, 0, 1], [1, 0, 0, 1]], dtype=np.float64)
+    a = oracle_mod.accel_f64_pps(pos, [0.3, 0.4], 0.0)
+    assert np.allclose(a[0], [1.25 ** -1.5, 0, 0], rtol=1e-14) and np.allclose(a[1], -a[0])
+    assert np.isclose(oracle_mod.potential_pps(pos, [0.3, 0.4], 0.0), -1.25 ** -0.5, rtol=1e-14)
+    rng = np.random.default_rng(8)
+    p = rng.normal(size=(200, 4))
+    p[:, 3] = rng.uniform(0.5, 1.5, 200)
+    e = 0.02
+    want = oracle_mod.accel_f64(p, eps=np.sqrt(1e-3 ** 2 + 2 * e * e), threads=1)
+    assert np.allclose(oracle_mod.accel_f64_pps(p, np.full(200, e), 1e-3), want, rtol=1e-12, atol=1e-14)
+    # an unsoftened coincident pair contributes nothing, as in pair_f64
+    p[1, :3] = p[0, :3]
+    assert np.isfinite(oracle_mod.accel_f64_pps(p, np.zeros(200), 0.0)).all()

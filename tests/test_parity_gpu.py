@@ -390,3 +390,68 @@ def test_kdk_matches_oracle_and_conserves_energy_better(nb, oracle_mod):
             s.kdk_kick_drift(1e-2)
         with pytest.raises(nb.NBodyError):
             s.kdk_kick(1e-2)
+
+
+# ---- per-particle softening (the vel.w the reference loads and never reads) --------------
+
+def pps_accel(nb, pos, eps_pp, eps, **kw):
+    n = pos.shape[0]
+    with nb.NBodySystem(n, **kw) as s:
+        s.set_particle_softening(eps_pp)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(np.zeros_like(pos))
+        s.step(1.0, eps)
+        return s.download()[1][:, :3]
+
+
+@pytest.mark.parametrize("n,eps", [(3000, 1e-3), (4097, 0.0)])
+def test_per_particle_softening_matches_oracle(nb, oracle_mod, n, eps):
+    pos, _ = nb.plummer(n, seed=41)
+    rng = np.random.default_rng(41)
+    eps_pp = rng.uniform(0.0, 0.05, n).astype(np.float32)
+    eps_pp[::7] = 0.0   # unsoftened bodies among softened ones
+    pos[11] = pos[10]   # a coincident pair: softened unless both lengths and eps are 0
+    got = pps_accel(nb, pos, eps_pp, eps)
+    want = oracle_mod.accel_f64_pps(pos, eps_pp, eps)
+    assert np.isfinite(got).all()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() / scale <= TOL
+    # equal lengths e are the global softening sqrt(eps^2 + 2 e^2), and 0 lengths are the plain kernel bit for bit
+    assert np.array_equal(pps_accel(nb, pos, np.zeros(n, np.float32), 1e-3), gpu_accel(nb, pos, 1e-3, rpl=-4))
+    e = np.float32(0.01)
+    uni = pps_accel(nb, pos, np.full(n, e, np.float32), 0.0)
+    glob = gpu_accel(nb, pos, float(np.sqrt(2.0) * e))
+    assert np.abs(uni - glob).max() / np.abs(glob).max() <= TOL
+
+
+def test_per_particle_softening_shards_energy_and_pair_once_refusal(nb, oracle_mod):
+    n, split_len = 6000, 512
+    pos, vel = nb.plummer(n, seed=42)
+    eps_pp = np.random.default_rng(42).uniform(0.0, 0.03, n).astype(np.float32)
+    whole = pps_accel(nb, pos, eps_pp, 1e-3, split_len=split_len)
+    import torch
+    eps_dev = torch.from_numpy(eps_pp).cuda()
+    parts = []
+    for lo, cnt in [(0, 2048), (2048, 2048), (4096, n - 4096)]:  # rows sharded; every shard sees every body's length
+        with nb.NBodySystem(n, row_lo=lo, row_count=cnt, split_len=split_len) as s:
+            s.set_particle_softening(eps_dev)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(np.zeros((cnt, 4), np.float32))
+            s.step(1.0, 1e-3)
+            parts.append(s.download()[1][:, :3])
+    assert np.array_equal(np.concatenate(parts), whole)
+    with nb.NBodySystem(n) as s:
+        s.set_particle_softening(eps_pp)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        e = s.energy(1e-3)
+        s.set_particle_softening(None)
+        e_plain = s.energy(1e-3)
+    assert np.isclose(e[1], oracle_mod.potential_pps(pos, eps_pp, 1e-3), rtol=1e-6)
+    assert np.allclose(e_plain, oracle_mod.energy(pos, vel, 1e-3), rtol=1e-6)
+    with nb.NBodySystem(16384, split_len=1024) as s:
+        s.set_force_mode("symmetric")
+        s.set_particle_softening(np.zeros(16384, np.float32))
+        s.setParticlesPosition(nb.plummer(16384, seed=1)[0])
+        with pytest.raises(nb.NBodyError):
+            s.step(1e-3, 1e-3)
