@@ -87,7 +87,7 @@ def pair_once_leg(nb, n, pos, vel, args):
     it: N^2/t for comparison, and the roofline fraction from the pair evaluations it actually executes."""
     import torch
     try:
-        s = nb.NBodySystem(n)
+        s = nb.NBodySystem(n, split_len=nb.PAIR_ONCE_SPLIT_LEN)
         s.set_force_mode("symmetric")
     except nb.NBodyError as e:
         return {"skipped": str(e)}
@@ -174,7 +174,8 @@ def main():
     n = args.n
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
     if world == 1:
-        system = nb.NBodySystem(n, device=local_rank)
+        system = nb.NBodySystem(n, device=local_rank,
+                                split_len=nb.PAIR_ONCE_SPLIT_LEN if args.force_mode == "symmetric" else 0)
         kernels = system
     else:
         system = ShardedNBodySystem(n, device=local_rank, exchange=args.exchange)

@@ -69,7 +69,9 @@ int main(int argc, char **argv)
         if (pad) nbody_io::pad_reference_style(b);  // accepted, never required (kernel.cu:260-278)
         std::printf("num of Bodies = %lld (real %lld)  dt = %g  softening = %g\n", (long long)b.n(), (long long)n_real, dt, softening);
 
-        nbody::System sys(b.n(), device);               // initialize(numBodies)
+        nbody::System sys;
+        if (pair_once) sys.initializeShard(b.n(), 0, b.n(), NBODY_PAIR_ONCE_SPLIT_LEN, device);
+        else sys.initialize(b.n(), device);             // initialize(numBodies)
         sys.setParticlesPosition(b.pos.data());
         sys.setParticlesVelocity(b.vel.data());
         sys.timing(true);

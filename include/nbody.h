@@ -152,9 +152,11 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
 /* Force algorithm.  NBODY_FORCE_ONE_SIDED (default): every ordered interaction is evaluated, rows are independent
  * (the shape of simple_update_all, kernel.cu:828-884; shards over GPUs).  NBODY_FORCE_SYMMETRIC (experimental): each
  * unordered pair once, applied to both bodies -- the idea of cal_acc_advanced, kernel.cu:703-774, without its float
- * atomics; single context only (all rows), 1024 <= split_len <= 8192, whole-range nbody_forces/nbody_step calls;
+ * atomics; single context only (all rows), 256 <= split_len <= 4096 (create the context with
+ * NBODY_PAIR_ONCE_SPLIT_LEN: small splits keep 5 workgroups on a CU), whole-range nbody_forces/nbody_step calls;
  * results agree with the default to rounding (not bit for bit) and are themselves bit-reproducible. */
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
+#define NBODY_PAIR_ONCE_SPLIT_LEN 2048
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 
 /* Per-particle softening: the reference loads a per-particle eps into velocities[4i+3]

@@ -75,9 +75,10 @@ def load() -> ctypes.CDLL:
     """Load the in-tree shared library; raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("NBODY_AMD_LIBRARY", LIB_PATH)  # an A/B build of the same ABI (tools/build_variant.sh)
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc, gfx950).  n_body_problem_amd has no CPU or PyTorch fallback.")
         try:
             # PyTorch-ROCm ships its own HIP runtime: let it load first so that this library binds to the same
@@ -85,7 +86,7 @@ def load() -> ctypes.CDLL:
             import torch  # noqa: F401
         except ImportError:  # a torch-free host (ctypes only) uses the system runtime
             pass
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res

@@ -23,7 +23,7 @@ struct nbody_ctx {
     bool acc_valid = false;
     const float *eps_pp = nullptr;  // per-particle softening lengths in use, n_total floats (borrowed or eps_own), or NULL
     float *eps_own = nullptr;       // the copy nbody_upload_particle_softening made
-    int2 *sym_tiles = nullptr;  // pair-once mode: the (I <= J) split pairs, one workgroup each
+    int2 *sym_tiles = nullptr;  // pair-once mode: the (I < J) split pairs, one workgroup each
     int sym_n_tiles = 0;
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
@@ -354,14 +354,14 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
     if (mode == NBODY_FORCE_SYMMETRIC) {
         if (c->row_lo != 0 || c->row_count != c->n_total)
             return fail(c, NBODY_ERR_INVALID, "nbody_set_force_mode: the pair-once mode needs all rows in one context");
-        if (c->split_len < 1024 || c->split_len > 8192)
+        if (c->split_len < 256 || c->split_len > 4096)
             return fail(c, NBODY_ERR_INVALID,
-                        "nbody_set_force_mode: the pair-once mode needs 1024 <= split_len <= 8192 (n_total >= 16384, "
-                        "or an explicit split_len at nbody_create_shard)");
-        if (!c->sym_tiles) {
-            std::vector<int2> tiles;
+                        "nbody_set_force_mode: the pair-once mode needs 256 <= split_len <= 4096 (create the context with "
+                        "split_len = NBODY_PAIR_ONCE_SPLIT_LEN)");
+        if (!c->sym_tiles && c->n_splits > 1) {
+            std::vector<int2> tiles;  // off-diagonal pairs; the diagonal has its own launch
             for (int i = 0; i < c->n_splits; ++i)
-                for (int j = i; j < c->n_splits; ++j)
+                for (int j = i + 1; j < c->n_splits; ++j)
                     tiles.push_back(make_int2(i, j));
             HIP_TRY(c, hipSetDevice(c->device));
             HIP_TRY(c, hipMalloc((void **)&c->sym_tiles, sizeof(int2) * tiles.size()));

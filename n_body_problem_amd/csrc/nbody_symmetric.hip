@@ -5,28 +5,34 @@
 // shared-memory and global float atomics -- which its author names as the bottleneck (kernel.cu:757) and which
 // make the result order-dependent.  This kernel keeps the idea and drops the atomics:
 //
-//   * tiles are pairs of column splits (I <= J), split_len bodies each; ONE 1024-thread workgroup (16 wave64) per
+//   * tiles are pairs of column splits (I <= J), split_len bodies each; ONE 256-thread workgroup (4 wave64) per
 //     tile, so every partial sum P[split][body] is produced by exactly one workgroup:
 //        rows b in I, columns c in J:  P[J][b] = sum_c m_c f(b,c)   (row side, registers)
 //                                      P[I][c] = -sum_b m_b f(b,c)  (column side, LDS)
 //     which is the SAME partial-sum array the one-sided kernel fills -- the update kernel does not change;
-//   * inside a wave, lane l owns R rows and at step s meets column (l+s) mod 64 of the wave's current 64-column
-//     group; the three column accumulators travel with the column, one lane per step (DPP wave_rol:1), so after 64
+//   * inside a wave, lane l owns 4 rows and at step s meets column (l+s) mod 64 of the wave's current 64-column
+//     group; the three column accumulators travel with the column, one lane per step (ds_bpermute_b32), so after 64
 //     steps column c's sum sits in lane c and is added to the LDS array without conflicts;
-//   * the 16 waves walk the column groups in a rotated order, G/16 groups apart, with a barrier every G/16 groups, so
+//   * the 4 waves walk the column groups in a rotated order, G/4 groups apart, with a barrier every G/4 groups, so
 //     no two waves touch the same LDS entries at a time and every entry receives its terms in a fixed order:
-//     bit-reproducible.
-//   * diagonal tiles (I == J) visit every (row, column) combination and keep the pairs with row index < column index.
+//     bit-reproducible;
+//   * small workgroups and <= 28 KiB of LDS (split_len 2048) put 5 workgroups = 5 waves per SIMD on a CU, enough for
+//     the idle-gap schedule of force_kernel_r4 to hide each wave's slow window after its
+//     v_rsq_f32 batch;
+//   * diagonal tiles (I == J) are a separate, compiler-scheduled kernel that visits every (row, column) combination
+//     and keeps the pairs with row index < column index (1/n_splits of the work).
 //
-// Per unordered pair: 3 sub, 3 fma, rsq, 4 mul, 6 fma = 16 VALU + 1 transcendental (+ 3 DPP moves per 64 x R pairs)
-// against 2 x (12 + 1) for the two ordered interactions it replaces.
+// Per unordered pair: 3 sub, 3 fma, rsq, 4 mul, 6 fma = 16 VALU + 1 transcendental (+ 3 DPP moves and 2 address
+// operations per 64 x 4 pairs) against 2 x (12 + 1) for the two ordered interactions it replaces.
 #include "nbody_kernels.h"
 
 namespace nbody {
 
-constexpr int kSymThreads = 1024;
+constexpr int kSymThreads = 256;
 constexpr int kSymWaves = kSymThreads / 64;
 constexpr int kSymRows = 4;  // rows per lane
+constexpr int kSymRowsPerPass = kSymWaves * 64 * kSymRows;
+constexpr int kSymStageFloats = kSymWaves * 64 * 4;  // one 64-body group (1 KiB, 1 KiB-aligned) per wave
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v)
@@ -38,113 +44,154 @@ __device__ __forceinline__ float dpp_move(float v)
 __device__ __forceinline__ float wave_rol1(float v) { return dpp_move<0x134>(v); }
 
 // ---- hand-allocated 64-step loop of an off-diagonal tile (same arithmetic and order as the C++ loop below) -----
-// Phases per step as in force_kernel_r4 (nbody_kernels.hip): 4 x (sub,sub,sub,fma,fma,fma) . 4 x v_rsq_f32 . next
-// ds_read_b128 . 4 x (4 mul, 6 fma) . rotate the column accumulators one lane.  No idle gap here: a 1024-thread
-// workgroup leaves 4 waves per SIMD, too few to hide it (measured: 0/8/16/24/32 wait states = 220/220/230/246/244 ms).
-// VGPR banks (index mod 4; src0/src1 never share one):
-//   v[2:5] / v[6:9]   column body {x,y,z,m} = banks 2,3,0,1, double-buffered        v10 = 1e-24 (GUARD)  v11 = eps^2
+// Phases per step as in force_kernel_r4 (nbody_kernels.hip): the next step's LDS address . 4 x (sub,sub,sub,fma,fma,
+// fma) . 4 x v_rsq_f32 . next ds_read_b128 . idle gap . 4 x (4 mul, 6 fma) . send the column accumulators one lane on.
+// VGPR banks (index mod 4): no instruction reads two sources from one bank, and an accumulating v_fmac counts its
+// destination as a source -- with the sums in the banks of dx,dy,dz this loop measured 18 conflicts x 2 cycles a step.
+//   v[2:5] / v[6:9]   column body {x,y,z,m} = banks 2,3,0,1, double-buffered
 //   row k=0..3        {x,y,z,m} = v[12+4k : 15+4k] = banks 0,1,2,3
 //   temps k           {dx,dy,dz, r2/inv/s_row} = v[28+4k : 31+4k] = banks 0,1,2,3
 //   shared            inv^2 = v44/v48 (bank 0)   inv^3 = v46/v50 (bank 2)   s_col = v47/v51 (bank 3)
-//   row sums          v52..v63      column sums v64,v65,v66 (travelling)     v0 = LDS byte address
+//   row sums k        az = v(52+4k) (bank 0)  ax = v(53+4k) (bank 1)  ay = v(54+4k) (bank 2)
+//   column sums       cx = v45 (bank 1)  cy = v68 (bank 0)  cz = v49 (bank 1)   (travelling)
+//   v11 = eps^2 (bank 3)   v69 = 1e-24 (GUARD, bank 1)   v59 = 4 * ((lane + 1) mod 64), the permute's source lane
+//   v0 = LDS byte address of the next read = v10 | (v1 & v55): v1 counts 16 bytes per step from 16*lane, v55 = 1023,
+//   v10 = the wave's 1 KiB-aligned group buffer -- column (lane + s) mod 64 without a second copy of the group.
 typedef float nb_f4 __attribute__((ext_vector_type(4)));
 #define SY_PRE(PX, PY, PZ, X, Y, Z, D0, D1, D2, R, GRD)                                                          \
     "v_sub_f32_e32 " D0 ", " PX ", " X "\n\tv_sub_f32_e32 " D1 ", " PY ", " Y "\n\tv_sub_f32_e32 " D2 ", " PZ ", " Z "\n\t" \
     "v_fma_f32 " R ", " D0 ", " D0 ", v11\n\tv_fmac_f32_e32 " R ", " D1 ", " D1 "\n\tv_fmac_f32_e32 " R ", " D2 ", " D2 "\n\t" GRD(R)
 #define SY_NOGUARD(R) ""
-#define SY_GUARD(R) "v_max_f32_e32 " R ", v10, " R "\n\t"
+#define SY_GUARD(R) "v_max_f32_e32 " R ", v69, " R "\n\t"
 #define SY_POST(PM, M, AX, AY, AZ, D0, D1, D2, R, Q, T, SC)                                                      \
     "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " T ", " R ", " Q "\n\t"                                      \
     "v_mul_f32_e32 " SC ", " M ", " T "\n\tv_mul_f32_e32 " R ", " PM ", " T "\n\t"                                    \
     "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t" \
-    "v_fmac_f32_e32 v64, " D0 ", " SC "\n\tv_fmac_f32_e32 v65, " D1 ", " SC "\n\tv_fmac_f32_e32 v66, " D2 ", " SC "\n\t"
+    "v_fmac_f32_e32 v45, " D0 ", " SC "\n\tv_fmac_f32_e32 v68, " D1 ", " SC "\n\tv_fmac_f32_e32 v49, " D2 ", " SC "\n\t"
+#ifndef NB_SYM_GAP
+#define NB_SYM_GAP "s_nop 11\n\t"
+#endif
+// The column sums move one lane per step through the LDS crossbar (ds_bpermute_b32, v59 = 4 * ((lane + 1) mod 64)):
+// three v_mov_b32_dpp wave_rol:1 measured 38 VALU cycles a step (tools/gen_sched2.py), the permutes 6.  LDS operations
+// of a wave complete in order, so "lgkmcnt(3)" at the top of a step means the column body has arrived (the three
+// permutes issued after it may still be in flight) and "lgkmcnt(1)" before the POST phase means the permutes have (the
+// next column's read may not).
+#define SY_ROTATE                                                                                                \
+    "ds_bpermute_b32 v45, v59, v45\n\tds_bpermute_b32 v68, v59, v68\n\tds_bpermute_b32 v49, v59, v49\n\t"
 #define SY_STEP(PX, PY, PZ, PM, NEXT, GRD)                                                                       \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    "v_add_u32_e32 v1, 16, v1\n\t"                                                                               \
+    "v_and_or_b32 v0, v1, v55, v10\n\t"                                                                          \
+    "s_waitcnt lgkmcnt(3)\n\t"                                                                                   \
     SY_PRE(PX, PY, PZ, "v12", "v13", "v14", "v28", "v29", "v30", "v31", GRD)                                     \
     SY_PRE(PX, PY, PZ, "v16", "v17", "v18", "v32", "v33", "v34", "v35", GRD)                                     \
     SY_PRE(PX, PY, PZ, "v20", "v21", "v22", "v36", "v37", "v38", "v39", GRD)                                     \
     SY_PRE(PX, PY, PZ, "v24", "v25", "v26", "v40", "v41", "v42", "v43", GRD)                                     \
     "v_rsq_f32_e32 v31, v31\n\tv_rsq_f32_e32 v35, v35\n\tv_rsq_f32_e32 v39, v39\n\tv_rsq_f32_e32 v43, v43\n\t"       \
     NEXT                                                                                                         \
-    SY_POST(PM, "v15", "v52", "v53", "v54", "v28", "v29", "v30", "v31", "v44", "v46", "v47")                     \
-    SY_POST(PM, "v19", "v55", "v56", "v57", "v32", "v33", "v34", "v35", "v48", "v50", "v51")                     \
-    SY_POST(PM, "v23", "v58", "v59", "v60", "v36", "v37", "v38", "v39", "v44", "v46", "v47")                     \
-    SY_POST(PM, "v27", "v61", "v62", "v63", "v40", "v41", "v42", "v43", "v48", "v50", "v51")                     \
-    "s_nop 1\n\t"                                                                                                \
-    "v_mov_b32_dpp v64, v64 wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"                                           \
-    "v_mov_b32_dpp v65, v65 wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"                                           \
-    "v_mov_b32_dpp v66, v66 wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"
+    NB_SYM_GAP                                                                                                   \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                   \
+    SY_POST(PM, "v15", "v53", "v54", "v52", "v28", "v29", "v30", "v31", "v44", "v46", "v47")                     \
+    SY_POST(PM, "v19", "v57", "v58", "v56", "v32", "v33", "v34", "v35", "v48", "v50", "v51")                     \
+    SY_POST(PM, "v23", "v61", "v62", "v60", "v36", "v37", "v38", "v39", "v44", "v46", "v47")                     \
+    SY_POST(PM, "v27", "v65", "v66", "v64", "v40", "v41", "v42", "v43", "v48", "v50", "v51")                     \
+    SY_ROTATE
 #define SY_GROUP_LOOP(GRD)                                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t" /* nothing of the compiler's may be counted by the waits below */                 \
+    "v_and_or_b32 v0, v1, v55, v10\n\t"                                                                          \
     "ds_read_b128 v[2:5], v0\n\t"                                                                                \
-    "s_mov_b32 %[cnt], 16\n"                                                                                     \
+    SY_ROTATE /* of zeros: primes the in-order LDS queue so that every step sees the same pattern */             \
+    "s_mov_b32 %[cnt], 32\n"                                                                                     \
     "1:\n\t"                                                                                                     \
-    SY_STEP("v2", "v3", "v4", "v5", "ds_read_b128 v[6:9], v0 offset:16\n\t", GRD)                                \
-    SY_STEP("v6", "v7", "v8", "v9", "ds_read_b128 v[2:5], v0 offset:32\n\t", GRD)                                \
-    SY_STEP("v2", "v3", "v4", "v5", "ds_read_b128 v[6:9], v0 offset:48\n\t", GRD)                                \
-    SY_STEP("v6", "v7", "v8", "v9", "v_add_u32_e32 v0, 64, v0\n\tds_read_b128 v[2:5], v0\n\t", GRD)               \
+    SY_STEP("v2", "v3", "v4", "v5", "ds_read_b128 v[6:9], v0\n\t", GRD)                                          \
+    SY_STEP("v6", "v7", "v8", "v9", "ds_read_b128 v[2:5], v0\n\t", GRD)                                          \
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
     "s_waitcnt lgkmcnt(0)\n"
 
-template <bool DIAG, bool GUARD>
-__device__ __forceinline__ void sym_tile(const SymArgs &a, int I, int J, float *sx, float *sy, float *sz, float4 *stage)
+struct SymLds {
+    float4 *stage;  // this wave's 64-body group
+    float *sx, *sy, *sz;
+};
+
+__device__ __forceinline__ SymLds sym_lds(float *smem, int L)
 {
+    SymLds s;
+    s.stage = reinterpret_cast<float4 *>(smem) + (threadIdx.x >> 6) * 64;
+    s.sx = smem + kSymStageFloats;
+    s.sy = s.sx + L;
+    s.sz = s.sy + L;
+    return s;
+}
+
+// The column group wave `wave` works on in round g: `spacing` groups after wave - 1, all walking the same way, so two
+// waves can only meet on a group if one gets `spacing` rounds ahead -- a barrier every `spacing` rounds rules that out
+// and fixes the order in which the waves' terms reach each LDS entry.
+__device__ __forceinline__ int sym_group(int g, int wave, int spacing, int G)
+{
+    int cg = g + spacing * wave;
+    while (cg >= G)
+        cg -= G;
+    return cg;
+}
+
+// ---- off-diagonal tiles (I < J) ------------------------------------------------------------------------------
+template <bool GUARD>
+__global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
+{
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int L = a.split_len, G = L / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rowbase = I * L, colbase = J * L;
-    const int rows_per_pass = kSymWaves * 64 * kSymRows;
+    const SymLds lds = sym_lds(smem, L);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int2 t = a.tiles[blockIdx.x];
+    const int rowbase = t.x * L, colbase = t.y * L;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float eps2;  // in a VGPR: an SGPR source operand costs an fp32 instruction two extra cycles on gfx950
-    asm volatile("v_mov_b32 %0, %1" : "=v"(eps2) : "s"(a.eps2));
+    const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
 
     for (int c = tid; c < L; c += kSymThreads)
-        sx[c] = sy[c] = sz[c] = 0.f;
+        lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
     __syncthreads();
 
-    for (int pass0 = 0; pass0 < L; pass0 += rows_per_pass) {
-        float x[kSymRows], y[kSymRows], z[kSymRows], m[kSymRows], ax[kSymRows], ay[kSymRows], az[kSymRows];
-        int rl[kSymRows];  // row index inside the split, or -1
+    for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
+        nb_f4 row[kSymRows];
+        float ax[kSymRows], ay[kSymRows], az[kSymRows];
 #pragma unroll
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             float4 p = zero4;
-            rl[k] = -1;
-            if (r < L && rowbase + r < a.n_total) {
+            if (r < L && rowbase + r < a.n_total)
                 p = a.pos[rowbase + r];
-                rl[k] = r;
-            }
-            x[k] = p.x; y[k] = p.y; z[k] = p.z; m[k] = p.w;
+            row[k] = nb_f4{p.x, p.y, p.z, p.w};
             ax[k] = ay[k] = az[k] = 0.f;
         }
 
-        // Wave w starts `spacing` groups after wave w-1 and all walk the groups in the same direction, so two waves
-        // can only meet on a group if one gets `spacing` rounds ahead: a barrier every `spacing` rounds rules that
-        // out and fixes the order in which the waves' terms reach each LDS entry.
-        const int spacing = G / kSymWaves;  // >= 1 (the host requires split_len >= 1024)
-        for (int g = 0; g < G; ++g) {
-            int cg = g + spacing * wave;
-            if (cg >= G)
-                cg -= G;
-            const int gc = colbase + cg * 64 + lane;
-            float4 c = zero4;
+        float4 cnext = zero4;  // the next group's column bodies, loaded a group ahead
+        {
+            const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + lane;
             if (gc < a.n_total)
-                c = a.pos[gc];
-            stage[lane] = c;       // twice, so that lane + s never wraps
-            stage[lane + 64] = c;
+                cnext = a.pos[gc];
+        }
+        for (int g = 0; g < G; ++g) {
+            const int cg = sym_group(g, wave, spacing, G);
+            lds.stage[lane] = cnext;
+            if (g + 1 < G) {
+                const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + lane;
+                cnext = zero4;
+                if (gc < a.n_total)
+                    cnext = a.pos[gc];
+            }
             float cx = 0.f, cy = 0.f, cz = 0.f;  // accumulators of column (lane + s) mod 64, travelling
-
-            if (!DIAG) {
-                unsigned lds = (unsigned)(size_t)(&stage[lane]);
-                unsigned cnt;
-                const nb_f4 r0 = {x[0], y[0], z[0], m[0]}, r1 = {x[1], y[1], z[1], m[1]};
-                const nb_f4 r2v = {x[2], y[2], z[2], m[2]}, r3 = {x[3], y[3], z[3], m[3]};
+            {
+                unsigned off = 16u * (unsigned)lane, addr = 0, cnt;
+                const unsigned base = (unsigned)(size_t)lds.stage, mask = 1023u, next_lane = 4u * ((lane + 1) & 63);
+                float eps2 = a.eps2;  // in a VGPR: an SGPR source operand costs an fp32 instruction two extra cycles
                 const float tiny = 1.0e-24f;
 #define SY_OPERANDS                                                                                                   \
-                : "+{v52}"(ax[0]), "+{v53}"(ay[0]), "+{v54}"(az[0]), "+{v55}"(ax[1]), "+{v56}"(ay[1]), "+{v57}"(az[1]),      \
-                  "+{v58}"(ax[2]), "+{v59}"(ay[2]), "+{v60}"(az[2]), "+{v61}"(ax[3]), "+{v62}"(ay[3]), "+{v63}"(az[3]),      \
-                  "+{v64}"(cx), "+{v65}"(cy), "+{v66}"(cz), "+{v0}"(lds), [cnt] "=&s"(cnt)                                 \
-                : "{v[12:15]}"(r0), "{v[16:19]}"(r1), "{v[20:23]}"(r2v), "{v[24:27]}"(r3), "{v11}"(eps2), "{v10}"(tiny)      \
+                : "+{v53}"(ax[0]), "+{v54}"(ay[0]), "+{v52}"(az[0]), "+{v57}"(ax[1]), "+{v58}"(ay[1]), "+{v56}"(az[1]),      \
+                  "+{v61}"(ax[2]), "+{v62}"(ay[2]), "+{v60}"(az[2]), "+{v65}"(ax[3]), "+{v66}"(ay[3]), "+{v64}"(az[3]),      \
+                  "+{v45}"(cx), "+{v68}"(cy), "+{v49}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)                  \
+                : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]), "{v11}"(eps2),     \
+                  "{v69}"(tiny), "{v10}"(base), "{v55}"(mask), "{v59}"(next_lane)                                                              \
                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",      \
                   "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v50", "v51", "scc",    \
                   "memory"
@@ -153,11 +200,79 @@ __device__ __forceinline__ void sym_tile(const SymArgs &a, int I, int J, float *
                 else
                     asm volatile(SY_GROUP_LOOP(SY_NOGUARD) SY_OPERANDS);
 #undef SY_OPERANDS
-            } else {
+            }
+            // after 64 rotations lane l holds column l of the group; force on the column body is -m_row * d * inv3
+            lds.sx[cg * 64 + lane] -= cx;
+            lds.sy[cg * 64 + lane] -= cy;
+            lds.sz[cg * 64 + lane] -= cz;
+#ifndef NB_SYM_NOBARRIER  // (timing experiments only)
+            if ((g + 1) % spacing == 0)
+                __syncthreads();
+#endif
+        }
+        __syncthreads();
+
+        float4 *out = a.partials + (size_t)t.y * a.n_total;  // row sums of this pass: P[J][row]
+#pragma unroll
+        for (int k = 0; k < kSymRows; ++k) {
+            const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
+            if (r < L && rowbase + r < a.n_total)
+                out[rowbase + r] = make_float4(ax[k], ay[k], az[k], 0.f);
+        }
+    }
+
+    float4 *out = a.partials + (size_t)t.x * a.n_total;  // column sums: P[I][column]
+    for (int c = tid; c < L; c += kSymThreads)
+        if (colbase + c < a.n_total)
+            out[colbase + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
+}
+
+// ---- diagonal tiles (I == J): rows and columns are the same bodies, keep row < column (drops the self pair too) ----
+template <bool GUARD>
+__global__ __launch_bounds__(kSymThreads) void force_sym_diag_kernel(SymArgs a)
+{
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int L = a.split_len, G = L / 64;
+    const SymLds lds = sym_lds(smem, L);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int base = blockIdx.x * L;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
+    float eps2;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(eps2) : "s"(a.eps2));
+
+    for (int c = tid; c < L; c += kSymThreads)
+        lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
+    __syncthreads();
+
+    for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
+        float x[kSymRows], y[kSymRows], z[kSymRows], m[kSymRows], ax[kSymRows], ay[kSymRows], az[kSymRows];
+        int rl[kSymRows];  // row index inside the split, or -1
+#pragma unroll
+        for (int k = 0; k < kSymRows; ++k) {
+            const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
+            float4 p = zero4;
+            rl[k] = -1;
+            if (r < L && base + r < a.n_total) {
+                p = a.pos[base + r];
+                rl[k] = r;
+            }
+            x[k] = p.x; y[k] = p.y; z[k] = p.z; m[k] = p.w;
+            ax[k] = ay[k] = az[k] = 0.f;
+        }
+        for (int g = 0; g < G; ++g) {
+            const int cg = sym_group(g, wave, spacing, G);
+            const int gc = base + cg * 64 + lane;
+            float4 c = zero4;
+            if (gc < a.n_total)
+                c = a.pos[gc];
+            lds.stage[lane] = c;
+            float cx = 0.f, cy = 0.f, cz = 0.f;
 #pragma unroll 4
             for (int s = 0; s < 64; ++s) {
-                // (prefetching the next step's column into a second register set measured 5 % slower)
-                const float4 pj = stage[lane + s];
+                const int cl = (lane + s) & 63;
+                const float4 pj = lds.stage[cl];
+                const int col = cg * 64 + cl;
 #pragma unroll
                 for (int k = 0; k < kSymRows; ++k) {
                     const float dx = pj.x - x[k], dy = pj.y - y[k], dz = pj.z - z[k];
@@ -168,10 +283,7 @@ __device__ __forceinline__ void sym_tile(const SymArgs &a, int I, int J, float *
                         r2 = __builtin_fmaxf(r2, 1.0e-24f);
                     const float inv = __builtin_amdgcn_rsqf(r2);
                     float inv3 = inv * (inv * inv);
-                    {  // rows and columns are the same bodies: keep row < column (drops the self pair too)
-                        const int col = cg * 64 + ((lane + s) & 63);
-                        inv3 = (rl[k] >= 0 && rl[k] < col) ? inv3 : 0.f;
-                    }
+                    inv3 = (rl[k] >= 0 && rl[k] < col) ? inv3 : 0.f;
                     const float sr = pj.w * inv3, sc = m[k] * inv3;
                     ax[k] = __builtin_fmaf(dx, sr, ax[k]);
                     ay[k] = __builtin_fmaf(dy, sr, ay[k]);
@@ -186,77 +298,60 @@ __device__ __forceinline__ void sym_tile(const SymArgs &a, int I, int J, float *
                 cy = wave_rol1(cy);
                 cz = wave_rol1(cz);
             }
-            }
-            // after 64 rotations lane l holds column l of the group; force on the column body is -m_row * d * inv3
-            sx[cg * 64 + lane] -= cx;
-            sy[cg * 64 + lane] -= cy;
-            sz[cg * 64 + lane] -= cz;
+            lds.sx[cg * 64 + lane] -= cx;
+            lds.sy[cg * 64 + lane] -= cy;
+            lds.sz[cg * 64 + lane] -= cz;
             if ((g + 1) % spacing == 0)
                 __syncthreads();
         }
         __syncthreads();
-
-        // row sums of this pass
-        if (DIAG) {
+        // row sums of this pass join the column sums of the same bodies
 #pragma unroll
-            for (int k = 0; k < kSymRows; ++k)
-                if (rl[k] >= 0) {
-                    sx[rl[k]] += ax[k];
-                    sy[rl[k]] += ay[k];
-                    sz[rl[k]] += az[k];
-                }
-        } else {
-            float4 *out = a.partials + (size_t)J * a.n_total;
-#pragma unroll
-            for (int k = 0; k < kSymRows; ++k)
-                if (rl[k] >= 0)
-                    out[rowbase + rl[k]] = make_float4(ax[k], ay[k], az[k], 0.f);
-        }
+        for (int k = 0; k < kSymRows; ++k)
+            if (rl[k] >= 0) {
+                lds.sx[rl[k]] += ax[k];
+                lds.sy[rl[k]] += ay[k];
+                lds.sz[rl[k]] += az[k];
+            }
         __syncthreads();
     }
 
-    float4 *out = a.partials + (size_t)I * a.n_total;
+    float4 *out = a.partials + (size_t)blockIdx.x * a.n_total;
     for (int c = tid; c < L; c += kSymThreads)
-        if (colbase + c < a.n_total)
-            out[colbase + c] = make_float4(sx[c], sy[c], sz[c], 0.f);
+        if (base + c < a.n_total)
+            out[base + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
-template <bool GUARD>
-__global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
+size_t symmetric_lds_bytes(int split_len) { return (size_t)split_len * 12 + (size_t)kSymStageFloats * sizeof(float); }
+
+template <typename K>
+static hipError_t sym_launch(K kernel, int blocks, size_t lds, const SymArgs &a, hipStream_t stream)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int L = a.split_len;
-    float *sx = smem, *sy = sx + L, *sz = sy + L;
-    float4 *stage = reinterpret_cast<float4 *>(sz + L) + (threadIdx.x >> 6) * 128;
-    const int2 t = a.tiles[blockIdx.x];
-    if (t.x == t.y)
-        sym_tile<true, GUARD>(a, t.x, t.y, sx, sy, sz, stage);
-    else
-        sym_tile<false, GUARD>(a, t.x, t.y, sx, sy, sz, stage);
+    if (blocks <= 0)
+        return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kSymThreads), lds, stream, a);
+    return hipGetLastError();
 }
-
-size_t symmetric_lds_bytes(int split_len) { return (size_t)split_len * 12 + (size_t)kSymWaves * 128 * sizeof(float4); }
 
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
 {
-    if (a.n_tiles <= 0)
-        return hipSuccess;
     const size_t lds = symmetric_lds_bytes(a.split_len);
+    const int n_splits = (a.n_total + a.split_len - 1) / a.split_len;
     hipError_t e;
     if (a.eps2 > 0.f) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&force_sym_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        hipLaunchKernelGGL(force_sym_kernel<false>, dim3(a.n_tiles), dim3(kSymThreads), lds, stream, a);
+        e = sym_launch(&force_sym_kernel<false>, a.n_tiles, lds, a, stream);
+        if (e == hipSuccess)
+            e = sym_launch(&force_sym_diag_kernel<false>, n_splits, lds, a, stream);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&force_sym_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        hipLaunchKernelGGL(force_sym_kernel<true>, dim3(a.n_tiles), dim3(kSymThreads), lds, stream, a);
+        e = sym_launch(&force_sym_kernel<true>, a.n_tiles, lds, a, stream);
+        if (e == hipSuccess)
+            e = sym_launch(&force_sym_diag_kernel<true>, n_splits, lds, a, stream);
     }
-    return hipGetLastError();
+    return e;
 }
 
 }  // namespace nbody

@@ -25,6 +25,7 @@ from ._lib import NBodyError, check
 #: the reference's compile-time constants (kernel.cu:63, :66 and SURVEY.md 8a for the effective values)
 TIME_TICK = 0.008
 SOFTENING_VERSION3 = 1.0e-2  # cal_single_acclerate_without_mass_new: 0.1 pre-scale => eps^2 = 1e-4
+PAIR_ONCE_SPLIT_LEN = 2048       # NBODY_PAIR_ONCE_SPLIT_LEN, include/nbody.h
 SOFTENING_VERSION1 = 1.0e-3  # cal_single_acclerate: eps^2 = EPSILON = 1e-6
 BLOCK_SIZE = 256
 

@@ -318,6 +318,34 @@ def test_full_size_n1048576_properties(nb, oracle_mod):
     assert np.all(np.abs(net) < 1e-5 * scale)
 
 
+def test_config5_size_n4194304_one_rank_of_eight(nb, oracle_mod):
+    """N = 2^22 (configs[4]) as rank 3 of 8 sees it: its 524288 rows against all 4.2e6 columns, one step.  A sample of
+    rows against the fp64 oracle, and the kick-drift of those rows."""
+    from n_body_problem_amd.sharded import shard_geometry
+    n, world, rank = 1 << 22, 8, 3
+    split_len = nb.default_split_len(n)
+    n_padded, chunk = shard_geometry(n, world, split_len)
+    assert n_padded == n and chunk == n // world
+    pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[5])
+    lo = rank * chunk
+    with nb.NBodySystem(n, row_lo=lo, row_count=chunk) as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step(1e-3, 1e-3)
+        new_pos, new_vel = s.download()
+    new_pos = new_pos[lo:lo + chunk]
+    assert new_vel.shape[0] == chunk
+    for off in (0, chunk // 2, chunk - 64):
+        a64 = oracle_mod.accel_f64(pos, i0=lo + off, i1=lo + off + 64, eps=1e-3)
+        v_want = vel[lo + off:lo + off + 64, :3].astype(np.float64) + 1e-3 * a64
+        x_want = pos[lo + off:lo + off + 64, :3].astype(np.float64) + 1e-3 * v_want
+        got_a = (new_vel[off:off + 64, :3].astype(np.float64) - vel[lo + off:lo + off + 64, :3]) / 1e-3
+        assert np.linalg.norm(got_a - a64) / np.linalg.norm(a64) < 1e-3   # a recovered through an fp32 velocity
+        assert np.abs(new_vel[off:off + 64, :3] - v_want).max() / np.abs(v_want).max() < TOL
+        assert np.abs(new_pos[off:off + 64, :3] - x_want).max() / np.abs(x_want).max() < TOL
+    assert np.array_equal(new_pos[:, 3], pos[lo:lo + chunk, 3])
+
+
 # ---- N1: the experimental pair-once (symmetric) force kernel ---------------------------------------------
 
 def sym_run(nb, pos, vel, dt, eps, steps, mode, split_len=0):
@@ -329,7 +357,8 @@ def sym_run(nb, pos, vel, dt, eps, steps, mode, split_len=0):
         return s.download()
 
 
-@pytest.mark.parametrize("n,split_len", [(16384, 1024), (20000, 1280), (5000, 1024), (65536, 4096), (262144, 0)])
+@pytest.mark.parametrize("n,split_len", [(16384, 1024), (20000, 1280), (5000, 1024), (3000, 256), (1500, 2048),
+                                         (65536, 4096), (262144, 2048)])
 def test_symmetric_mode_matches_oracle_and_one_sided(nb, oracle_mod, n, split_len):
     pos, vel = nb.uniform_cube(n, seed=200 + n, random_masses=True, speed=0.2) if n < 30000 else nb.plummer(n, seed=n)
     zero = np.zeros_like(vel)
@@ -355,7 +384,7 @@ def test_symmetric_mode_zero_softening_and_limits(nb):
     a = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "symmetric", 1024)[1][:, :3]
     b = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "one_sided", 1024)[1][:, :3]
     assert np.all(np.isfinite(a)) and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
-    with nb.NBodySystem(4096) as s:                   # split_len = 256 < 1024
+    with nb.NBodySystem(1 << 20) as s:                # default split_len = 8192 > 4096
         with pytest.raises(nb.NBodyError):
             s.set_force_mode("symmetric")
     with nb.NBodySystem(32768, row_lo=0, row_count=16384) as s:

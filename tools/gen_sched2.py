@@ -119,6 +119,82 @@ for nreg, tag in ((72, "7 waves"), (80, "6 waves"), (96, "5 waves"), (128, "4 wa
         add(f"b4_n{t}_r{nreg}", f"4 rsq batched, {t} wait states, {tag}", al, batched(al, nops(t)), 4)
 
 
+# ---- the pair-once step (nbody_symmetric.hip): 16 fp32 + rsq per pair, 4 rows per lane, per-step extras ------------
+class SymAlloc:
+    """The register map of nbody_symmetric.hip's SY_STEP (banks: see the comment there)."""
+    nreg = 72
+    R, U = 4, 1
+
+
+def sym_step(gap, rotate=True, addr=True, post_order="row", halves=False):
+    """rotate: True/"wave_rol" = 3 x v_mov_b32_dpp wave_rol:1; "row_ror" = 3 x v_mov_b32_dpp row_ror:1 (cost probe);
+    "bpermute" = 3 x ds_bpermute_b32 through the LDS crossbar, waited for just before the POST phase."""
+    px, py, pz, pm = "v2", "v3", "v4", "v5"
+    pre, rsq, post = [], [], []
+    for k in range(4):
+        X, Y, Z, M = (f"v{12+4*k+c}" for c in range(4))
+        D0, D1, D2, Rr = (f"v{28+4*k+c}" for c in range(4))
+        AZ, AX, AY = (f"v{52+4*k+c}" for c in range(3))
+        Q, T, SC = ("v44", "v46", "v47") if k % 2 == 0 else ("v48", "v50", "v51")
+        pre.append([f"v_sub_f32_e32 {D0}, {px}, {X}", f"v_sub_f32_e32 {D1}, {py}, {Y}", f"v_sub_f32_e32 {D2}, {pz}, {Z}",
+                    f"v_fma_f32 {Rr}, {D0}, {D0}, v11", f"v_fmac_f32_e32 {Rr}, {D1}, {D1}", f"v_fmac_f32_e32 {Rr}, {D2}, {D2}"])
+        rsq.append([f"v_rsq_f32_e32 {Rr}, {Rr}"])
+        post.append([f"v_mul_f32_e32 {Q}, {Rr}, {Rr}", f"v_mul_f32_e32 {T}, {Rr}, {Q}", f"v_mul_f32_e32 {SC}, {M}, {T}",
+                     f"v_mul_f32_e32 {Rr}, {pm}, {T}", f"v_fmac_f32_e32 {AX}, {D0}, {Rr}", f"v_fmac_f32_e32 {AY}, {D1}, {Rr}",
+                     f"v_fmac_f32_e32 {AZ}, {D2}, {Rr}", f"v_fmac_f32_e32 v45, {D0}, {SC}", f"v_fmac_f32_e32 v68, {D1}, {SC}",
+                     f"v_fmac_f32_e32 v49, {D2}, {SC}"])
+    body = []
+    if addr:
+        body += ["v_add_u32_e32 v1, 16, v1", "v_and_or_b32 v0, v1, v55, v10"]
+    if rotate == "bpermute":
+        body += ["s_waitcnt lgkmcnt(3)"]
+    groups = [(0, 1), (2, 3)] if halves else [(0, 1, 2, 3)]
+    for grp in groups:
+        for k in grp:
+            body += pre[k]
+        for k in grp:
+            body += rsq[k]
+        body += nops(gap)
+        if rotate == "bpermute":
+            body += ["s_waitcnt lgkmcnt(0)"]
+        if post_order == "row":
+            for k in grp:
+                body += post[k]
+        else:  # stage by stage across the rows
+            for i in range(10):
+                for k in grp:
+                    body.append(post[k][i])
+    if rotate == "bpermute":
+        body += [f"ds_bpermute_b32 {r}, v59, {r}" for r in ("v45", "v68", "v49")]
+    elif rotate:
+        ctrl = "row_ror:1" if rotate == "row_ror" else "wave_rol:1"
+        body += ["s_nop 1"] + [f"v_mov_b32_dpp {r}, {r} {ctrl} row_mask:0xf bank_mask:0xf" for r in ("v45", "v68", "v49")]
+    return body
+
+
+for nreg, tag in ((96, "5 waves"), (128, "4 waves"), (64, "8 waves")):
+    for gap in (0, 12, 24):
+        al = SymAlloc()
+        al.nreg = max(nreg, 72)
+        if nreg == 64 and gap != 12:
+            continue
+        add(f"sym_g{gap}_r{nreg}", f"pair-once step, arithmetic only, gap {gap}, {tag} (floor 40.8/pair)", al,
+            sym_step(gap, rotate=False, addr=False), 2)
+al = SymAlloc(); al.nreg = 96
+add("sym_full", "pair-once step + 3 DPP + 2 address ops, gap 12, 5 waves", al, sym_step(12), 2)
+add("sym_dpp", "pair-once step + 3 DPP, gap 12, 5 waves", al, sym_step(12, addr=False), 2)
+add("sym_rowror", "pair-once step + 3 DPP row_ror:1 (cost probe), gap 12", al, sym_step(12, rotate="row_ror", addr=False), 2)
+add("sym_bperm", "pair-once step + 3 ds_bpermute_b32, gap 12", al, sym_step(12, rotate="bpermute", addr=False), 2)
+add("sym_bperm_full", "pair-once step + 3 ds_bpermute_b32 + 2 address ops, gap 12", al, sym_step(12, rotate="bpermute"), 2)
+add("sym_bperm_full24", "pair-once step + 3 ds_bpermute_b32 + 2 address ops, gap 24", al, sym_step(24, rotate="bpermute"), 2)
+al80 = SymAlloc(); al80.nreg = 80
+add("sym_bperm_full_r80", "pair-once step + 3 ds_bpermute_b32 + 2 address ops, gap 12, 80 regs", al80, sym_step(12, rotate="bpermute"), 2)
+add("sym_full_r80", "pair-once step + 3 DPP wave_rol + 2 address ops, gap 12, 80 regs", al80, sym_step(12), 2)
+add("sym_stage", "pair-once step, POST stage by stage, gap 12, 5 waves", al, sym_step(12, rotate=False, addr=False, post_order="stage"), 2)
+add("sym_halves", "pair-once step, two 2-row half batches, gap 12 each, 5 waves", al, sym_step(12, rotate=False, addr=False, halves=True), 2)
+add("sym_halves0", "pair-once step, two 2-row half batches, no gap, 5 waves", al, sym_step(0, rotate=False, addr=False, halves=True), 2)
+
+
 TEMPLATE = r'''// GENERATED by tools/gen_sched2.py -- do not edit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
