@@ -4,14 +4,19 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (force accumulation over all N x N ordered pairs + kick-drift
+A "step" is one pass of the hot path (the forces of all N x N ordered body-body interactions + kick-drift
 update) over one synthetic Plummer-sphere state resident in HBM.  Rank 0 prints ONE JSON line.
 
 * value     = N^2 * K / wall time of K steps (max over ranks, barrier + synchronize on both sides).
-* roofline  = the force kernel against the fp32 vector peak: 20 flop per interaction x the
-              interactions one launch evaluates / its HIP-event duration, measured in this run on the stream
-              the kernel runs on.  The kernel is VALU-bound; "traffic" is the HBM bytes per step from the
-              committed rocprofv3 PMC summary when one exists for this size, else null.
+* --force-mode pair_once (default): nbody::force_sym_kernel evaluates each unordered pair once and applies it to
+              both bodies (the reference's own VERSION 3 idea, kernel.cu:703-774, without atomics); one_sided:
+              nbody::force_kernel_r4 evaluates every ordered interaction.  Both on 1..8 GPUs; at N = 1 the other mode
+              is timed too and reported in "other_force_mode".
+* roofline  = the dominant force kernel against the fp32 vector peak: ALGORITHMIC flop = 20 per ordered interaction
+               x the interactions one launch accounts for / its HIP-event duration, measured in this
+              run on the stream the kernel runs on.  The pair-once kernel EXECUTES fewer (26 flop per unordered pair):
+              "frac_executed" says how busy the VALU really is.  "traffic" is the HBM bytes per launch from the
+              committed rocprofv3 PMC summary when one exists for this kernel and size, else null.
 * cpu_baseline = the CPU oracle's scalar all-pairs loop (a port; the reference has no CPU path), timed on this
               host's cores on a row slab of the same workload (N = 1 run only).
 Multi-GPU: total N is fixed, rows are sharded over the ranks => "scaling": "strong".
@@ -30,6 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_INTERACTION = 20.0        # SURVEY.md 8d (GPU Gems 3 ch.31 convention)
+FLOP_PER_PAIR_ONCE = 26.0          # executed by force_sym_kernel per unordered pair: 3 sub, 9 fma, 4 mul, 1 rsq
+KERNEL_NAME = {"one_sided": "nbody::force_kernel_r4", "pair_once": "nbody::force_sym_kernel"}
 PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md, chip-level parameters: 256 CU x 4 SIMD x 32 lanes x 2 x 2.4 GHz
 
 
@@ -82,15 +89,40 @@ def reference_size_leg(nb):
             "speedup_vs_reference_comment": 1.6 / ms}
 
 
-def pair_once_leg(nb, n, pos, vel, args):
-    """The experimental pair-once kernel on the same state, reported BESIDE the headline, never as
-    it: N^2/t for comparison, and the roofline fraction from the pair evaluations it actually executes."""
+def executed_pairs(mode, n, split_len, rows_here):
+    """Pair evaluations rank 0's force launches execute per step."""
+    if mode == "one_sided":
+        return rows_here * n
+    S = -(-n // split_len)
+    return (S * (S - 1) / 2 + S) * split_len * split_len * rows_here / n   # off-diagonal tiles + the diagonal ones
+
+
+def roofline(mode, n, split_len, rows_here, steps, tm):
+    force_s = max(tm["force_ms"] / 1e3, 1e-12)
+    launches = max(tm["force_launches"], 1)
+    algorithmic = FLOP_PER_INTERACTION * rows_here * n * steps
+    executed = executed_pairs(mode, n, split_len, rows_here) * steps
+    executed_flop = (FLOP_PER_INTERACTION if mode == "one_sided" else FLOP_PER_PAIR_ONCE) * executed
+    achieved = algorithmic / force_s / 1e12
+    traffic = committed_traffic(n, KERNEL_NAME[mode]) if rows_here == n else None
+    return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+            "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
+            "kernel": KERNEL_NAME[mode],
+            "algorithmic_flop_per_launch": algorithmic / launches,
+            "executed_pair_evaluations_per_s": executed / force_s,
+            "frac_executed": executed_flop / force_s / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+            "avg_launch_ms": tm["force_ms"] / launches, "launches": tm["force_launches"],
+            "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used; algorithmic = 20 flop "
+                    "per ordered interaction (SURVEY.md 8d); executed = 20 per ordered (one_sided) or 26 per unordered "
+                    "(pair_once) pair evaluation; rank 0's kernels"}
+
+
+def other_mode_leg(nb, mode, n, pos, vel, args):
+    """The force mode that is NOT the headline, on the same state and GPU (N = 1 run only)."""
     import torch
-    try:
-        s = nb.NBodySystem(n, split_len=nb.PAIR_ONCE_SPLIT_LEN)
-        s.set_force_mode("symmetric")
-    except nb.NBodyError as e:
-        return {"skipped": str(e)}
+    s = nb.NBodySystem(n, split_len=nb.PAIR_ONCE_SPLIT_LEN if mode == "pair_once" else 0)
+    s.set_force_mode(mode)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel)
     s.timing(True)
@@ -105,27 +137,21 @@ def pair_once_leg(nb, n, pos, vel, args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = s.read_timing()
-    L = s.split_len
-    S = -(-n // L)
-    executed = S * (S + 1) / 2 * L * L * steps
+    out = {"force_mode": mode, "value": float(n) * n * steps / dt, "unit": "interactions/s", "ms_per_step": 1e3 * dt / steps,
+           "steps": steps, "roofline": roofline(mode, n, s.split_len, n, steps, tm)}
     s.close()
-    force_s = max(tm["force_ms"] / 1e3, 1e-12)
-    return {"value": float(n) * n * steps / dt, "unit": "interactions/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "kernel": "nbody::force_sym_kernel", "executed_pair_evaluations_per_s": executed / force_s,
-            "roofline_frac_executed": FLOP_PER_INTERACTION * executed / force_s / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-            "note": "each unordered pair once, applied to both bodies; single GPU only; agrees with the headline kernel "
-                    "to rounding (tests/test_parity_gpu.py), bit-reproducible; NOT the headline value"}
+    return out
 
 
-def committed_traffic(n):
-    """HBM bytes per step from a committed PMC summary (profiles/*pmc*.json) for this body count, if any."""
+def committed_traffic(n, kernel):
+    """HBM bytes per launch from a committed PMC summary (profiles/*pmc*.json) for this kernel and body count, if any."""
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("n") == n and "hbm_bytes_per_force_launch" in d:
+        if d.get("n") == n and "hbm_bytes_per_force_launch" in d and d.get("kernel", "").split("<")[0] in kernel:
             best = (d["hbm_bytes_per_force_launch"], os.path.basename(f))
     return best
 
@@ -140,15 +166,18 @@ def main():
     ap.add_argument("--softening", type=float, default=1e-3)
     ap.add_argument("--exchange", default=os.environ.get("NBODY_EXCHANGE", "allgather"), choices=["allgather", "ring"])
     ap.add_argument("--rows-per-lane", type=int, default=0)
-    ap.add_argument("--force-mode", default="one_sided", choices=["one_sided", "symmetric"],
-                    help="symmetric = the experimental pair-once kernel (1 GPU only); roofline from EXECUTED pair evaluations")
+    ap.add_argument("--force-mode", default=os.environ.get("NBODY_FORCE_MODE", "pair_once"),
+                    choices=["pair_once", "one_sided", "symmetric"],
+                    help="pair_once (= symmetric): each unordered pair once; one_sided: every ordered interaction")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pair-once", action="store_true", help="skip the extra leg that times the experimental pair-once kernel")
+    ap.add_argument("--no-extra-legs", "--no-pair-once", dest="no_extra_legs", action="store_true",
+                    help="skip the extra legs (the other force mode, the reference's N = 20000)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the product path); gloo only to rehearse the multi-rank flow on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
+    mode = "pair_once" if args.force_mode == "symmetric" else args.force_mode
 
     import torch
     import torch.distributed as dist
@@ -174,17 +203,13 @@ def main():
     n = args.n
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
     if world == 1:
-        system = nb.NBodySystem(n, device=local_rank,
-                                split_len=nb.PAIR_ONCE_SPLIT_LEN if args.force_mode == "symmetric" else 0)
+        system = nb.NBodySystem(n, device=local_rank, split_len=nb.PAIR_ONCE_SPLIT_LEN if mode == "pair_once" else 0)
+        system.set_force_mode(mode)
         kernels = system
     else:
-        system = ShardedNBodySystem(n, device=local_rank, exchange=args.exchange)
+        system = ShardedNBodySystem(n, device=local_rank, exchange=args.exchange, force_mode=mode)
         kernels = system.kernels
     kernels.set_rows_per_lane(args.rows_per_lane)
-    if args.force_mode != "one_sided":
-        if world != 1:
-            raise SystemExit("--force-mode symmetric is single-GPU")
-        kernels.set_force_mode(args.force_mode)
     system.setParticlesPosition(pos)
     system.setParticlesVelocity(vel)
     info = kernels.device_info()
@@ -217,17 +242,7 @@ def main():
     if rank == 0:
         interactions = float(n) * float(n) * args.steps
         rows_here = n / world
-        force_s = tm["force_ms"] / 1e3
-        launches = max(tm["force_launches"], 1)
-        # executed pair evaluations: N^2 ordered ones, or (S(S+1)/2) x split_len^2 unordered ones in the pair-once mode
-        executed = rows_here * n * args.steps
-        if args.force_mode == "symmetric":
-            L = kernels.split_len
-            S = -(-n // L)
-            executed = S * (S + 1) / 2 * L * L * args.steps
-        flop_per_launch = FLOP_PER_INTERACTION * executed / launches
-        achieved = FLOP_PER_INTERACTION * executed / max(force_s, 1e-12) / 1e12
-        traffic = committed_traffic(n) if world == 1 and args.force_mode == "one_sided" else None
+        force_s = max(tm["force_ms"] / 1e3, 1e-12)
         out = {
             "metric": "body-body interactions/sec",
             "value": interactions / elapsed,
@@ -242,29 +257,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"all-pairs step, N={n} Plummer sphere (BASELINE.json configs[2]), fp32, "
-                                   f"softening={args.softening}, dt={args.dt}, LDS tile=256",
+                                   f"softening={args.softening}, dt={args.dt}",
                        "n_bodies": n, "parallelism": f"rows sharded x{world}" if world > 1 else "1 GPU",
                        "exchange": args.exchange if world > 1 else None,
                        "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
                        "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3],
-                       "force_mode": args.force_mode},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                         "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "nbody::force_kernel" if args.force_mode == "one_sided" else "nbody::force_sym_kernel",
-                         "executed_pair_evaluations_per_s": executed / max(force_s, 1e-12),
-                         "flop_per_launch": flop_per_launch,
-                         "avg_launch_ms": tm["force_ms"] / launches, "launches": tm["force_launches"],
-                         "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used; "
-                                 "20 flop per ordered interaction; rank 0's kernels"},
-            "force_only_interactions_per_s": rows_here * n * args.steps / max(force_s, 1e-12) * world,
+                       "force_mode": mode},
+            "roofline": roofline(mode, n, int(getattr(system, "split_len", 0)), rows_here, args.steps, tm),
+            "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
             "update_ms_per_step": tm["update_ms"] / args.steps,
             "device": info,
         }
-        if world == 1 and args.force_mode == "one_sided" and not args.no_pair_once:
-            out["pair_once"] = pair_once_leg(nb, n, pos, vel, args)
-        if world == 1 and args.force_mode == "one_sided" and not args.no_pair_once:
+        if world == 1 and not args.no_extra_legs:
+            out["other_force_mode"] = other_mode_leg(nb, "one_sided" if mode == "pair_once" else "pair_once", n, pos, vel, args)
             out["reference_size"] = reference_size_leg(nb)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, args.softening, args.cpu_seconds)

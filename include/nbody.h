@@ -150,14 +150,28 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
                       int64_t *update_launches);
 
 /* Force algorithm.  NBODY_FORCE_ONE_SIDED (default): every ordered interaction is evaluated, rows are independent
- * (the shape of simple_update_all, kernel.cu:828-884; shards over GPUs).  NBODY_FORCE_SYMMETRIC (experimental): each
- * unordered pair once, applied to both bodies -- the idea of cal_acc_advanced, kernel.cu:703-774, without its float
- * atomics; single context only (all rows), 256 <= split_len <= 4096 (create the context with
- * NBODY_PAIR_ONCE_SPLIT_LEN: small splits keep 5 workgroups on a CU), whole-range nbody_forces/nbody_step calls;
- * results agree with the default to rounding (not bit for bit) and are themselves bit-reproducible. */
+ * (the shape of simple_update_all, kernel.cu:828-884).  NBODY_FORCE_SYMMETRIC ("pair-once"): each unordered pair once,
+ * applied to both bodies -- the idea of cal_acc_advanced, kernel.cu:703-774, without its float atomics.  Needs
+ * 256 <= split_len <= 4096 (create the context with NBODY_PAIR_ONCE_SPLIT_LEN: small splits keep 5 workgroups on a
+ * CU).  Results agree with the default to rounding (not bit for bit) and are themselves bit-reproducible, and
+ * identical for 1, 2, 4 or 8 contexts sharing the rows: the partial sums are added in NBODY_SYM_GROUPS groups of
+ * ceil(n_splits / 8) splits, a sharded context must own whole groups, and per step
+ *     nbody_forces / nbody_forces_complement   (as in the default mode: any split-aligned column ranges)
+ *     nbody_sym_reduce                          (column-side sums of the context's groups, for every body)
+ *     [all-gather the contexts' slices of the colparts buffer -- the caller's job, e.g. RCCL]
+ *     nbody_update / nbody_kdk_*                (adds row-side and column-side sums in the fixed order)
+ * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
 #define NBODY_PAIR_ONCE_SPLIT_LEN 2048
+#define NBODY_SYM_GROUPS 8
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
+/* The exchange buffer of the pair-once mode: NBODY_SYM_GROUPS x n_total x float4 on the device, group-major.
+ * d_buf is borrowed (NULL: a buffer the context owns -- enough for a single context).  nbody_sym_reduce writes the
+ * slices [group_lo, group_lo + group_count) x n_total (nbody_sym_groups); the other slices must hold the other
+ * contexts' sums before nbody_update. */
+int nbody_sym_set_colparts(nbody_ctx *ctx, float *d_buf);
+int nbody_sym_groups(const nbody_ctx *ctx, int64_t *group_lo, int64_t *group_count, int64_t *group_splits);
+int nbody_sym_reduce(nbody_ctx *ctx);
 
 /* Per-particle softening: the reference loads a per-particle eps into velocities[4i+3]
  * (kernel.cu:223, 237) and no kernel ever reads it.  With d_eps (n_total floats on the device, borrowed until replaced;

@@ -23,18 +23,52 @@ struct ForceArgs {
     const float *eps_pp; // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
 };
 
-// EXPERIMENTAL pair-once kernel (nbody_symmetric.hip): one workgroup per pair of splits (I <= J).
+// Pair-once kernel (nbody_symmetric.hip): one workgroup per ordered pair of splits (R, C), R's bodies as rows (one
+// context's own rows), C's bodies as columns; each unordered pair {R, C} is computed once, by the owner of the side
+// sym_rows_side() names.
+constexpr int kSymGroups = 8;  // the canonical summation: 8 groups of ceil(n_splits / 8) splits, see sym_finalize
+
+// True when the tile of the unordered split pair {R, C} (R != C) is computed with R's bodies as rows: the "forward
+// half" of the ring of S splits, so every split is the row side of (S - 1) / 2 tiles -- equal work for every rank that
+// owns equally many splits.  A pure function of (R, C, S): the summation kernels use it to know which partial sums exist.
+__host__ __device__ inline bool sym_rows_side(int R, int C, int S)
+{
+    int d = C - R;
+    if (d < 0)
+        d += S;
+    if (d == 0)
+        return false;
+    if (2 * d != S)
+        return 2 * d < S;
+    const int lo = R < C ? R : C;  // S even, opposite splits: alternate
+    return ((lo & 1) == 0) == (R == lo);
+}
+
 struct SymArgs {
-    const float4 *pos;   // all n_total bodies
-    float4 *partials;    // [n_splits][n_total]
-    const int2 *tiles;   // n_tiles pairs (I, J), I <= J
+    const float4 *pos;     // all n_total bodies
+    float4 *row_partials;  // [n_splits][row_count]: P_row[C][b] = force on own body b from the bodies of split C
+    float4 *col_partials;  // [own splits][n_total]: P_col[R][c] = force on body c (any rank's) from own split R
+    const int2 *tiles;     // n_tiles pairs (R, C), R an own split, R != C
     int n_tiles;
+    const int2 *diag_tiles;  // n_diag pairs (B, B), own splits: every pair inside the split once, both sides
+    int n_diag;
     int n_total;
-    int split_len;       // 1024 <= split_len <= 8192, multiple of 256
+    int split_len;         // 256 <= split_len <= 4096, multiple of 256
+    int row_lo, row_count; // the context's own rows (whole splits)
     float eps2;
 };
-hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);
+hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);       // the tiles (R != C)
+hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream);  // the diagonal tiles
 size_t symmetric_lds_bytes(int split_len);
+
+// colparts[g][c] = sum over the own splits R of group g (ascending, where the tile (R, C(c)) exists) of P_col[R][c],
+// for the own groups [group_lo, group_lo + group_count) and every body c.  colparts is [kSymGroups][n_total].
+hipError_t launch_sym_colparts(const float4 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
+                               int split_lo, int group_splits, int group_lo, int group_count, hipStream_t stream);
+// acc[b] = sum over the groups g (ascending) of ( sum over C in g (ascending, where the tile (B(b), C) exists, and the
+// diagonal C == B(b)) of P_row[C][b]  +  colparts[g][b] ): the same association for any number of ranks.
+hipError_t launch_sym_finalize(const float4 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
+                               int n_total, int split_len, int n_splits, int group_splits, hipStream_t stream);
 
 // Partial accelerations of rows [row_lo,row_lo+row_count) from splits [split_first, split_first+split_count).
 // rows_per_lane in {1,2,4,8}.  eps2 == 0 selects the zero-distance-guarded variant.

@@ -5,11 +5,13 @@
 // shared-memory and global float atomics -- which its author names as the bottleneck (kernel.cu:757) and which
 // make the result order-dependent.  This kernel keeps the idea and drops the atomics:
 //
-//   * tiles are pairs of column splits (I <= J), split_len bodies each; ONE 256-thread workgroup (4 wave64) per
-//     tile, so every partial sum P[split][body] is produced by exactly one workgroup:
-//        rows b in I, columns c in J:  P[J][b] = sum_c m_c f(b,c)   (row side, registers)
-//                                      P[I][c] = -sum_b m_b f(b,c)  (column side, LDS)
-//     which is the SAME partial-sum array the one-sided kernel fills -- the update kernel does not change;
+//   * tiles are pairs of splits (R, C), split_len bodies each; ONE 256-thread workgroup (4 wave64) per tile, so every
+//     partial sum is produced by exactly one workgroup:
+//        rows b in R, columns c in C:  P_row[C][b] = sum_c m_c f(b,c)   (row side, registers)
+//                                      P_col[R][c] = -sum_b m_b f(b,c)  (column side, LDS)
+//     each unordered pair {R, C} is one tile, with the side sym_rows_side() names as rows -- so that the tiles of a
+//     context that owns the rows of some splits are exactly the ones with R among them (sharding over GPUs: the
+//     P_col of remote bodies are summed per group of splits, exchanged once per step and added in a fixed order);
 //   * inside a wave, lane l owns 4 rows and at step s meets column (l+s) mod 64 of the wave's current 64-column
 //     group; the three column accumulators travel with the column, one lane per step (ds_bpermute_b32), so after 64
 //     steps column c's sum sits in lane c and is added to the LDS array without conflicts;
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
     const int rowbase = t.x * L, colbase = t.y * L;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
+    const int row_hi = min(a.row_lo + a.row_count, a.n_total);
 
     for (int c = tid; c < L; c += kSymThreads)
         lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             float4 p = zero4;
-            if (r < L && rowbase + r < a.n_total)
+            if (r < L && rowbase + r < row_hi)
                 p = a.pos[rowbase + r];
             row[k] = nb_f4{p.x, p.y, p.z, p.w};
             ax[k] = ay[k] = az[k] = 0.f;
@@ -212,16 +215,16 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
         }
         __syncthreads();
 
-        float4 *out = a.partials + (size_t)t.y * a.n_total;  // row sums of this pass: P[J][row]
+        float4 *out = a.row_partials + (size_t)t.y * a.row_count;  // row sums of this pass: P_row[C][row]
 #pragma unroll
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
-            if (r < L && rowbase + r < a.n_total)
-                out[rowbase + r] = make_float4(ax[k], ay[k], az[k], 0.f);
+            if (r < L && rowbase + r < row_hi)
+                out[rowbase + r - a.row_lo] = make_float4(ax[k], ay[k], az[k], 0.f);
         }
     }
 
-    float4 *out = a.partials + (size_t)t.x * a.n_total;  // column sums: P[I][column]
+    float4 *out = a.col_partials + (size_t)(t.x - a.row_lo / L) * a.n_total;  // column sums: P_col[R][column]
     for (int c = tid; c < L; c += kSymThreads)
         if (colbase + c < a.n_total)
             out[colbase + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_diag_kernel(SymArgs a)
     const int L = a.split_len, G = L / 64;
     const SymLds lds = sym_lds(smem, L);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int base = blockIdx.x * L;
+    const int split = a.diag_tiles[blockIdx.x].x;
+    const int base = split * L;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
     float eps2;
@@ -316,10 +320,10 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_diag_kernel(SymArgs a)
         __syncthreads();
     }
 
-    float4 *out = a.partials + (size_t)blockIdx.x * a.n_total;
+    float4 *out = a.row_partials + (size_t)split * a.row_count;  // both sides of the split: P_row[B][b]
     for (int c = tid; c < L; c += kSymThreads)
         if (base + c < a.n_total)
-            out[base + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
+            out[base + c - a.row_lo] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
 size_t symmetric_lds_bytes(int split_len) { return (size_t)split_len * 12 + (size_t)kSymStageFloats * sizeof(float); }
@@ -340,18 +344,89 @@ static hipError_t sym_launch(K kernel, int blocks, size_t lds, const SymArgs &a,
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
 {
     const size_t lds = symmetric_lds_bytes(a.split_len);
-    const int n_splits = (a.n_total + a.split_len - 1) / a.split_len;
-    hipError_t e;
-    if (a.eps2 > 0.f) {
-        e = sym_launch(&force_sym_kernel<false>, a.n_tiles, lds, a, stream);
-        if (e == hipSuccess)
-            e = sym_launch(&force_sym_diag_kernel<false>, n_splits, lds, a, stream);
-    } else {
-        e = sym_launch(&force_sym_kernel<true>, a.n_tiles, lds, a, stream);
-        if (e == hipSuccess)
-            e = sym_launch(&force_sym_diag_kernel<true>, n_splits, lds, a, stream);
+    return a.eps2 > 0.f ? sym_launch(&force_sym_kernel<false>, a.n_tiles, lds, a, stream)
+                        : sym_launch(&force_sym_kernel<true>, a.n_tiles, lds, a, stream);
+}
+
+hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream)
+{
+    const size_t lds = symmetric_lds_bytes(a.split_len);
+    return a.eps2 > 0.f ? sym_launch(&force_sym_diag_kernel<false>, a.n_diag, lds, a, stream)
+                        : sym_launch(&force_sym_diag_kernel<true>, a.n_diag, lds, a, stream);
+}
+
+// ---- the canonical summation of the pair-once partial sums (HBM-bound, O(N n_splits)) ------------------------------
+// The order is the same for 1, 2, 4 or 8 ranks: kSymGroups groups of `group_splits` consecutive splits; a rank owns
+// whole groups, sums the column-side terms of each of its groups for EVERY body (sym_colparts_kernel; that is what
+// the ranks exchange), and the owner of a body adds, group by group, its row-side terms of the group and the group's
+// column-side sum (sym_finalize_kernel).
+
+__global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float4 *col_partials, float4 *colparts, int n_total,
+                                                             int split_len, int n_splits, int split_lo, int group_splits,
+                                                             int group_lo)
+{
+    const int c = blockIdx.x * kTile + threadIdx.x;
+    const int g = group_lo + blockIdx.y;
+    if (c >= n_total)
+        return;
+    const int C = c / split_len;  // uniform in the workgroup (split_len is a multiple of kTile)
+    const int r0 = g * group_splits, r1 = min(r0 + group_splits, n_splits);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int R = r0; R < r1; ++R)
+        if (sym_rows_side(R, C, n_splits)) {
+            const float4 v = col_partials[(size_t)(R - split_lo) * n_total + c];
+            sx += v.x;
+            sy += v.y;
+            sz += v.z;
+        }
+    colparts[(size_t)g * n_total + c] = make_float4(sx, sy, sz, 0.f);
+}
+
+__global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float4 *row_partials, const float4 *colparts, float4 *acc,
+                                                             int row_lo, int row_count, int n_total, int split_len,
+                                                             int n_splits, int group_splits)
+{
+    const int b = blockIdx.x * kTile + threadIdx.x;
+    if (b >= row_count)
+        return;
+    const int B = (row_lo + b) / split_len;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int g = 0; g * group_splits < n_splits; ++g) {
+        const int c0 = g * group_splits, c1 = min(c0 + group_splits, n_splits);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int C = c0; C < c1; ++C)
+            if (C == B || sym_rows_side(B, C, n_splits)) {
+                const float4 v = row_partials[(size_t)C * row_count + b];
+                sx += v.x;
+                sy += v.y;
+                sz += v.z;
+            }
+        const float4 cp = colparts[(size_t)g * n_total + row_lo + b];
+        ax += sx + cp.x;
+        ay += sy + cp.y;
+        az += sz + cp.z;
     }
-    return e;
+    acc[b] = make_float4(ax, ay, az, 0.f);
+}
+
+hipError_t launch_sym_colparts(const float4 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
+                               int split_lo, int group_splits, int group_lo, int group_count, hipStream_t stream)
+{
+    if (n_total <= 0 || group_count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sym_colparts_kernel, dim3((n_total + kTile - 1) / kTile, group_count), dim3(kTile), 0, stream,
+                       col_partials, colparts, n_total, split_len, n_splits, split_lo, group_splits, group_lo);
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_finalize(const float4 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
+                               int n_total, int split_len, int n_splits, int group_splits, hipStream_t stream)
+{
+    if (row_count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sym_finalize_kernel, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, row_partials,
+                       colparts, acc, row_lo, row_count, n_total, split_len, n_splits, group_splits);
+    return hipGetLastError();
 }
 
 }  // namespace nbody

@@ -35,6 +35,28 @@ def shard_geometry(num_bodies: int, world_size: int, split_len: int):
     return chunk * world_size, chunk
 
 
+def pair_once_geometry(num_bodies: int, world_size: int, split_len: int):
+    """(padded body count, rows per rank) of the pair-once mode: the partial sums are added in SYM_GROUPS groups of
+    ceil(n_splits / SYM_GROUPS) splits and a rank owns whole groups, so the world size must divide SYM_GROUPS."""
+    groups = _system.SYM_GROUPS
+    if groups % world_size:
+        raise ValueError(f"the pair-once mode shards over 1, 2, 4 or 8 ranks, not {world_size}")
+    n_splits = max(1, -(-num_bodies // split_len))
+    group_splits = -(-n_splits // groups)
+    return groups * group_splits * split_len, (groups // world_size) * group_splits * split_len
+
+
+def sym_rows_side(r: int, c: int, n_splits: int) -> bool:
+    """nbody::sym_rows_side (csrc/nbody_kernels.h): is the tile of the split pair {r, c} computed with r's bodies as rows?"""
+    d = (c - r) % n_splits
+    if d == 0:
+        return False
+    if 2 * d != n_splits:
+        return 2 * d < n_splits
+    lo = min(r, c)
+    return ((lo & 1) == 0) == (r == lo)
+
+
 def ring_schedule(rank: int, world_size: int):
     """[(hop, chunk sent to rank+1, chunk received from rank-1)] for hops 1..P-1 of a ring all-gather."""
     return [(h, (rank - h + 1) % world_size, (rank - h) % world_size) for h in range(1, world_size)]
@@ -50,7 +72,8 @@ class ShardedNBodySystem:
     """
 
     def __init__(self, num_bodies: int, group=None, device: Optional[int] = None, exchange: str = "allgather",
-                 kernels_factory: Optional[Callable] = None, split_len: int = 0, integrator: str = "kick_drift"):
+                 kernels_factory: Optional[Callable] = None, split_len: int = 0, integrator: str = "kick_drift",
+                 force_mode: str = "one_sided"):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -58,8 +81,11 @@ class ShardedNBodySystem:
             raise ValueError("exchange must be 'allgather' or 'ring'")
         if integrator not in ("kick_drift", "kdk"):
             raise ValueError("integrator must be 'kick_drift' or 'kdk'")
+        if force_mode not in ("one_sided", "pair_once"):
+            raise ValueError("force_mode must be 'one_sided' or 'pair_once'")
         self.exchange = exchange
         self.integrator = integrator
+        self.force_mode = force_mode
         self._kdk_ready = False  # kdk: accelerations at the current positions are cached in the kernels object
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
@@ -67,12 +93,14 @@ class ShardedNBodySystem:
         self.world_size = dist.get_world_size(group) if self.distributed else 1
         self.num_bodies = int(num_bodies)
         if kernels_factory is None:
-            self.split_len = int(split_len) or _system.default_split_len(self.num_bodies)
+            self.split_len = int(split_len) or (_system.PAIR_ONCE_SPLIT_LEN if force_mode == "pair_once" else
+                                                _system.default_split_len(self.num_bodies))
         else:
             if not split_len:
                 raise ValueError("a custom kernels_factory needs an explicit split_len")
             self.split_len = int(split_len)
-        self.n_padded, self.chunk = shard_geometry(self.num_bodies, self.world_size, self.split_len)
+        geometry = pair_once_geometry if force_mode == "pair_once" else shard_geometry
+        self.n_padded, self.chunk = geometry(self.num_bodies, self.world_size, self.split_len)
         self.row_lo = self.rank * self.chunk
         if kernels_factory is None:
             dev = torch.cuda.current_device() if device is None else device
@@ -80,6 +108,14 @@ class ShardedNBodySystem:
                                                split_len=self.split_len)
         else:
             self.kernels = kernels_factory(self.n_padded, self.row_lo, self.chunk, self.split_len)
+        self._cp_send = None
+        if force_mode == "pair_once":
+            # each unordered pair once (nbody_symmetric.hip): besides the positions, the ranks exchange the sums of the
+            # forces their rows put on everybody else's bodies -- SYM_GROUPS / P slices of (n_padded, 4) floats per rank
+            # and step (16 MiB at N = 2^20, P = 8), one all-gather between the force kernels and the update
+            self.kernels.set_force_mode("pair_once")
+            if self.world_size > 1:
+                self._cp_send = torch.empty_like(self.kernels.sym_own_slice())
         self.positions = self.kernels.positions      # full replica, (n_padded, 4)
         self.velocities = self.kernels.velocities    # own rows, (chunk, 4)
         self._on_gpu = bool(self.positions.is_cuda)
@@ -236,6 +272,16 @@ class ShardedNBodySystem:
             self._drain()
             k.forces_complement(lo, self.chunk, softening)
 
+    def _sum_forces(self) -> None:
+        """Pair-once mode: the column-side sums of this rank's groups, for every body, gathered from every rank."""
+        if self.force_mode != "pair_once":
+            return
+        k = self.kernels
+        k.sym_reduce()
+        if self.world_size > 1:
+            self._cp_send.copy_(k.sym_own_slice())
+            self._dist.all_gather_into_tensor(k.colparts, self._cp_send, group=self.group)
+
     def _exchange_own_rows(self) -> None:
         if self.world_size > 1:
             if self.exchange == "allgather":
@@ -251,16 +297,19 @@ class ShardedNBodySystem:
             # runs beside the exchange
             if not self._kdk_ready:
                 self._forces_all_columns(softening)
+                self._sum_forces()
                 k.kdk_prepare()
                 self._kdk_ready = True
             k.kdk_kick_drift(dt)
             self._exchange_own_rows()
             self._forces_all_columns(softening)
+            self._sum_forces()
             k.kdk_kick(dt)
             if sync:
                 self.sync()
             return
         self._forces_all_columns(softening)
+        self._sum_forces()
         k.update(dt)
         self._exchange_own_rows()
         if sync:

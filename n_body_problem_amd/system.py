@@ -26,6 +26,7 @@ from ._lib import NBodyError, check
 TIME_TICK = 0.008
 SOFTENING_VERSION3 = 1.0e-2  # cal_single_acclerate_without_mass_new: 0.1 pre-scale => eps^2 = 1e-4
 PAIR_ONCE_SPLIT_LEN = 2048       # NBODY_PAIR_ONCE_SPLIT_LEN, include/nbody.h
+SYM_GROUPS = 8                   # NBODY_SYM_GROUPS
 SOFTENING_VERSION1 = 1.0e-3  # cal_single_acclerate: eps^2 = EPSILON = 1e-6
 BLOCK_SIZE = 256
 
@@ -217,9 +218,31 @@ class NBodySystem:
                 "update_launches": u_n.value}
 
     def set_force_mode(self, mode: str) -> None:
-        """``"one_sided"`` (default) or ``"symmetric"`` (experimental pair-once kernel, single context only)."""
-        code = {"one_sided": 0, "symmetric": 1}[mode]
+        """``"one_sided"`` (default) or ``"symmetric"`` (the pair-once kernel; create the system with
+        ``split_len=PAIR_ONCE_SPLIT_LEN``).  A shard in the pair-once mode exchanges ``self.colparts`` once per step:
+        ``forces*`` -> ``sym_reduce()`` -> all-gather of ``sym_own_slice()`` -> ``update``."""
+        code = {"one_sided": 0, "symmetric": 1, "pair_once": 1}[mode]
         check(self._lib.nbody_set_force_mode(self._ctx, code), self._ctx)
+        self.colparts = None
+        if code == 1 and (self.row_lo != 0 or self.row_count != self.num_bodies):
+            torch = _torch()  # the exchange buffer lives in a tensor so that torch.distributed can gather into it
+            self.colparts = torch.zeros((SYM_GROUPS, self.num_bodies, 4), dtype=torch.float32, device=self.device)
+            check(self._lib.nbody_sym_set_colparts(self._ctx, _ptr(self.colparts)), self._ctx)
+
+    def sym_groups(self):
+        """(first group, group count, splits per group) of this context in the pair-once summation order."""
+        lo, cnt, gs = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.nbody_sym_groups(self._ctx, ctypes.byref(lo), ctypes.byref(cnt), ctypes.byref(gs)), self._ctx)
+        return lo.value, cnt.value, gs.value
+
+    def sym_own_slice(self):
+        """The slices of ``colparts`` this context writes (a view): what it contributes to the all-gather."""
+        lo, cnt, _ = self.sym_groups()
+        return self.colparts[lo:lo + cnt]
+
+    def sym_reduce(self) -> None:
+        self._use_current_stream()
+        check(self._lib.nbody_sym_reduce(self._ctx), self._ctx)
 
     def set_particle_softening(self, eps) -> None:
         """Per-particle softening lengths for ALL bodies (host array or device tensor of ``num_bodies`` floats), e.g.

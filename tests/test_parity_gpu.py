@@ -378,6 +378,44 @@ def test_symmetric_mode_matches_oracle_and_one_sided(nb, oracle_mod, n, split_le
     assert rel_state_error(p1, pr) < 1e-6 and rel_state_error(v1, vr) < 1e-6
 
 
+def test_symmetric_mode_row_shards_with_a_manual_exchange(nb):
+    """Two contexts in one process share the rows (4 + 4 groups); the column sums are exchanged by copying the slices
+    each context wrote: bit-identical to the single context, for the pair-once summation order is fixed."""
+    n, L = 16384, 512                                 # 32 splits, 8 groups of 4
+    pos, vel = nb.plummer(n, seed=77)
+    want = sym_run(nb, pos, vel, 1e-3, 1e-3, 2, "symmetric", L)
+    a = nb.NBodySystem(n, row_lo=0, row_count=n // 2, split_len=L)
+    b = nb.NBodySystem(n, row_lo=n // 2, row_count=n // 2, split_len=L)
+    for s in (a, b):
+        s.set_force_mode("symmetric")
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+    assert a.sym_groups() == (0, 4, 4) and b.sym_groups() == (4, 4, 4)
+    for _ in range(2):
+        for s in (a, b):
+            s.forces(s.row_lo, s.row_count, 1e-3)     # own columns first, then the rest, as the sharded host does
+            s.forces_complement(s.row_lo, s.row_count, 1e-3)
+            s.sym_reduce()
+        a.colparts[4:8].copy_(b.colparts[4:8])
+        b.colparts[0:4].copy_(a.colparts[0:4])
+        for s in (a, b):
+            s.update(1e-3)
+        a.positions[n // 2:].copy_(b.positions[n // 2:])
+        b.positions[:n // 2].copy_(a.positions[:n // 2])
+    pa, va = a.download()
+    pb, vb = b.download()
+    assert np.array_equal(pa, want[0]) and np.array_equal(pb, want[0])
+    assert np.array_equal(np.concatenate([va, vb]), want[1])
+    with pytest.raises(nb.NBodyError):                # a shard cannot update before its sym_reduce
+        a.forces(0, n, 1e-3)
+        a.update(1e-3)
+    a.close()
+    b.close()
+    with nb.NBodySystem(n, row_lo=L, row_count=4 * L, split_len=L) as s:   # rows must be whole groups
+        with pytest.raises(nb.NBodyError):
+            s.set_force_mode("symmetric")
+
+
 def test_symmetric_mode_zero_softening_and_limits(nb):
     pos, vel = nb.uniform_cube(16384, seed=9, random_masses=True)
     pos[5] = pos[6]                                   # two coincident bodies
@@ -385,9 +423,6 @@ def test_symmetric_mode_zero_softening_and_limits(nb):
     b = sym_run(nb, pos, np.zeros_like(vel), 1.0, 0.0, 1, "one_sided", 1024)[1][:, :3]
     assert np.all(np.isfinite(a)) and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
     with nb.NBodySystem(1 << 20) as s:                # default split_len = 8192 > 4096
-        with pytest.raises(nb.NBodyError):
-            s.set_force_mode("symmetric")
-    with nb.NBodySystem(32768, row_lo=0, row_count=16384) as s:
         with pytest.raises(nb.NBodyError):
             s.set_force_mode("symmetric")
 

@@ -80,3 +80,46 @@ def test_two_ranks_kdk_reproduce_one_rank(tmp_path, oracle_mod):
     pos, vel = ic.plummer(n, seed=1234)
     pr, vr = oracle_mod.step_kdk_f32(pos, vel, 1e-3, 1e-2, nsteps=steps)
     assert rel_state_error(one["p"], pr) < 1e-6 and rel_state_error(one["v"], vr) < 1e-6
+
+
+def test_pair_once_geometry_and_tile_orientation():
+    from n_body_problem_amd.sharded import pair_once_geometry, sym_rows_side
+    assert pair_once_geometry(1 << 20, 8, 2048) == (1 << 20, 131072)      # 512 splits, 8 groups of 64
+    assert pair_once_geometry(1 << 20, 1, 2048) == (1 << 20, 1 << 20)
+    assert pair_once_geometry(1000, 2, 256) == (2048, 1024)               # 4 splits -> 8 groups of 1 (4 of padding)
+    assert pair_once_geometry(20000, 4, 256) == (20480, 5120)             # 79 splits -> 8 groups of 10
+    with pytest.raises(ValueError):
+        pair_once_geometry(1000, 3, 256)
+    for S in (1, 2, 5, 8, 16, 79):
+        rows = [0] * S
+        for r in range(S):
+            assert not sym_rows_side(r, r, S)
+            for c in range(r + 1, S):
+                assert sym_rows_side(r, c, S) != sym_rows_side(c, r, S)   # every unordered pair exactly once
+                rows[r if sym_rows_side(r, c, S) else c] += 1
+        assert max(rows) - min(rows) <= 1                                 # and the same work for every split
+
+
+@pytest.mark.parametrize("world,exchange,integrator", [(2, "allgather", "kick_drift"), (2, "ring", "kick_drift"),
+                                                       (4, "allgather", "kdk")])
+def test_pair_once_ranks_reproduce_one_rank_bit_for_bit(tmp_path, oracle_mod, world, exchange, integrator):
+    """The pair-once data flow (row sums, column sums, per-group reduction, one all-gather, fixed summation order) under
+    gloo: 2 and 4 ranks end with the bits of the one-rank run."""
+    import torch.multiprocessing as mp
+    n, split_len, steps = 1000, 256, 2
+    out = str(tmp_path)
+    run_rank(0, 1, 0, exchange, n, split_len, steps, out, integrator, "pair_once")
+    mp.spawn(run_rank, args=(world, free_port(), exchange, n, split_len, steps, out, integrator, "pair_once"),
+             nprocs=world, join=True)
+    tag = (exchange if integrator == "kick_drift" else exchange + "_" + integrator) + "_pair_once"
+    one = np.load(os.path.join(out, f"w1_{tag}_r0.npz"))
+    assert int(one["n_padded"]) == 2048
+    for r in range(world):
+        g = np.load(os.path.join(out, f"w{world}_{tag}_r{r}.npz"))
+        assert int(g["chunk"]) == 2048 // world
+        assert np.array_equal(g["p"], one["p"]) and np.array_equal(g["v"], one["v"])
+    from n_body_problem_amd import initial_conditions as ic
+    pos, vel = ic.plummer(n, seed=1234)
+    step = oracle_mod.step_f32 if integrator == "kick_drift" else oracle_mod.step_kdk_f32
+    pr, vr = step(pos, vel, 1e-3, 1e-2, nsteps=steps)
+    assert rel_state_error(one["p"], pr) < 1e-6 and rel_state_error(one["v"], vr) < 1e-6

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Condenses a gpurun_out/prof_<tag>/ directory (written by tools/profile.sh on the GPU box) into the
 tracked summaries under profiles/:  <round>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats) and
-<round>_pmc_n<N>.json (per-launch PMC counters of nbody::force_kernel with the gfx950 corrections of
-MI355X_MICROARCH.md: FETCH_SIZE is in KiB and reads HALF the bytes of a 16-B/lane coalesced stream)."""
+<round>_pmc[_<mode>]_n<N>.json (per-launch PMC counters of the dominant force kernel with the gfx950 corrections of
+MI355X_MICROARCH.md: FETCH_SIZE is in KiB and reads HALF the bytes of a 16-B/lane coalesced stream).
+
+    python tools/summarize_prof.py <tag> <round> [N] [kernel substring: force_kernel_r4 | force_sym_kernel] [mode tag]"""
 import csv
 import glob
 import json
@@ -14,28 +16,28 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(tag, rnd, n):
+def main(tag, rnd, n, kern="force_kernel", mode=""):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{rnd}_kernel_stats.csv"))
-    out = {"n": n, "round": rnd, "kernel": "nbody::force_kernel", "source": f"tools/profile.sh {tag} (rocprofv3, separate --pmc passes)"}
+        shutil.copy(stats[0], os.path.join(dst, f"{rnd}_kernel_stats{'_' + mode if mode else ''}.csv"))
+    out = {"n": n, "round": rnd, "kernel": "nbody::" + kern, "source": f"tools/profile.sh {tag} (rocprofv3, separate --pmc passes)"}
     counters = defaultdict(list)
     durations = []
     vgpr = None
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
-                if "force_kernel" in r["Kernel_Name"]:
+                if kern in r["Kernel_Name"]:
                     counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     vgpr = r.get("VGPR_Count")
                     out["kernel_name"] = r["Kernel_Name"]
                     out["lds_block_size"] = int(r["LDS_Block_Size"])
     for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
-            if "force_kernel" in r["Kernel_Name"]:
+            if kern in r["Kernel_Name"]:
                 durations.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     mean = {k: sum(v) / len(v) for k, v in counters.items()}
     out["counters_per_launch"] = mean
@@ -58,14 +60,15 @@ def main(tag, rnd, n):
         if "SQ_WAVE_CYCLES" in mean:
             out["mean_waves_per_simd"] = mean["SQ_WAVE_CYCLES"] * 4.0 / (cyc * 1024.0)
         if "SQ_INSTS_VALU" in mean:
-            inter = float(n) * float(n) / 64.0
+            inter = float(n) * float(n) / 64.0   # wave64 instructions' worth of ORDERED interactions
             out["valu_instructions_per_interaction"] = mean["SQ_INSTS_VALU"] / inter
             out["simd_cycles_per_interaction"] = cyc * 1024.0 / inter
     out["vgpr_count_reported"] = vgpr
-    path = os.path.join(dst, f"{rnd}_pmc_n{n}.json")
+    path = os.path.join(dst, f"{rnd}_pmc{'_' + mode if mode else ''}_n{n}.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20,
+         sys.argv[4] if len(sys.argv) > 4 else "force_kernel", sys.argv[5] if len(sys.argv) > 5 else "")
