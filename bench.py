@@ -121,7 +121,7 @@ def roofline(mode, n, split_len, rows_here, steps, tm):
 def other_mode_leg(nb, mode, n, pos, vel, args):
     """The force mode that is NOT the headline, on the same state and GPU (N = 1 run only)."""
     import torch
-    s = nb.NBodySystem(n, split_len=nb.PAIR_ONCE_SPLIT_LEN if mode == "pair_once" else 0)
+    s = nb.NBodySystem(n, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0)
     s.set_force_mode(mode)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel)
@@ -203,7 +203,7 @@ def main():
     n = args.n
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
     if world == 1:
-        system = nb.NBodySystem(n, device=local_rank, split_len=nb.PAIR_ONCE_SPLIT_LEN if mode == "pair_once" else 0)
+        system = nb.NBodySystem(n, device=local_rank, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0)
         system.set_force_mode(mode)
         kernels = system
     else:

@@ -70,7 +70,7 @@ int main(int argc, char **argv)
         std::printf("num of Bodies = %lld (real %lld)  dt = %g  softening = %g\n", (long long)b.n(), (long long)n_real, dt, softening);
 
         nbody::System sys;
-        if (pair_once) sys.initializeShard(b.n(), 0, b.n(), NBODY_PAIR_ONCE_SPLIT_LEN, device);
+        if (pair_once) sys.initializeShard(b.n(), 0, b.n(), nbody_pair_once_split_len(b.n()), device);
         else sys.initialize(b.n(), device);             // initialize(numBodies)
         sys.setParticlesPosition(b.pos.data());
         sys.setParticlesVelocity(b.vel.data());

@@ -152,8 +152,8 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
 /* Force algorithm.  NBODY_FORCE_ONE_SIDED (default): every ordered interaction is evaluated, rows are independent
  * (the shape of simple_update_all, kernel.cu:828-884).  NBODY_FORCE_SYMMETRIC ("pair-once"): each unordered pair once,
  * applied to both bodies -- the idea of cal_acc_advanced, kernel.cu:703-774, without its float atomics.  Needs
- * 256 <= split_len <= 4096 (create the context with NBODY_PAIR_ONCE_SPLIT_LEN: small splits keep 5 workgroups on a
- * CU).  Results agree with the default to rounding (not bit for bit) and are themselves bit-reproducible, and
+ * 256 <= split_len <= 4096 (create the context with nbody_pair_once_split_len(n_total): small splits keep 5
+ * workgroups on a CU).  Results agree with the default to rounding (not bit for bit) and are themselves bit-reproducible, and
  * identical for 1, 2, 4 or 8 contexts sharing the rows: the partial sums are added in NBODY_SYM_GROUPS groups of
  * ceil(n_splits / 8) splits, a sharded context must own whole groups, and per step
  *     nbody_forces / nbody_forces_complement   (as in the default mode: any split-aligned column ranges)
@@ -162,7 +162,11 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
  *     nbody_update / nbody_kdk_*                (adds row-side and column-side sums in the fixed order)
  * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
-#define NBODY_PAIR_ONCE_SPLIT_LEN 2048
+/* The split length to create a pair-once context with.  A function of n_total ONLY (split boundaries define the
+ * summation order, so they must not depend on the sharding): 1024 up to 2^20 bodies -- the kernel's rows-per-pass, the
+ * finest grid that keeps every wave busy -- then 2048 and 4096 so that the two partial-sum arrays
+ * (n_splits x n_total x 16 B each, over all contexts) stay under about 40 GB. */
+int64_t nbody_pair_once_split_len(int64_t n_total);
 #define NBODY_SYM_GROUPS 8
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 /* The exchange buffer of the pair-once mode: NBODY_SYM_GROUPS x n_total x float4 on the device, group-major.

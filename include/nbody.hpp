@@ -70,7 +70,7 @@ public:
     {
         check(nbody_set_integrator(ctx_, on ? NBODY_INTEGRATOR_KDK : NBODY_INTEGRATOR_KICK_DRIFT), "nbody_set_integrator");
     }
-    // experimental pair-once force kernel (single context created with splitLen = NBODY_PAIR_ONCE_SPLIT_LEN)
+    // experimental pair-once force kernel (context created with splitLen = nbody_pair_once_split_len(numBodies))
     void setPairOnce(bool on)
     {
         check(nbody_set_force_mode(ctx_, on ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED), "nbody_set_force_mode");

@@ -62,6 +62,7 @@ _PROTOTYPES = {
     "nbody_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
                                   POINTER(c_int64)]),
     "nbody_set_force_mode": (c_int, [c_void_p, c_int]),
+    "nbody_pair_once_split_len": (ctypes.c_int64, [ctypes.c_int64]),
     "nbody_sym_set_colparts": (c_int, [c_void_p, c_void_p]),
     "nbody_sym_groups": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_int64)]),

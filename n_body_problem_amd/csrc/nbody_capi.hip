@@ -104,6 +104,18 @@ int64_t nbody_default_split_len(int64_t n_total)
     return len > 8192 ? 8192 : len;
 }
 
+int64_t nbody_pair_once_split_len(int64_t n_total)
+{
+    // 1024 = the pair-once kernel's rows per pass (4 waves x 64 lanes x 4 rows): shorter splits idle waves, longer ones
+    // coarsen the grid (at N = 2^20 one of 8 ranks measured 24.4 ms per step with 1024, 25.8 with 2048, 46.9 with 512;
+    // N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms).  The partial sums cost n_total^2 / split_len x 16 B twice.
+    const double need = (double)n_total * (double)n_total / 2.5e9;
+    int64_t len = 1024;
+    while (len < 4096 && (double)len < need)
+        len *= 2;
+    return len;
+}
+
 int64_t nbody_split_len(const nbody_ctx *ctx) { return ctx ? ctx->split_len : 0; }
 int64_t nbody_n_total(const nbody_ctx *ctx) { return ctx ? ctx->n_total : 0; }
 
@@ -370,7 +382,7 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         if (c->split_len < 256 || c->split_len > 4096)
             return fail(c, NBODY_ERR_INVALID,
                         "nbody_set_force_mode: the pair-once mode needs 256 <= split_len <= 4096 (create the context with "
-                        "split_len = NBODY_PAIR_ONCE_SPLIT_LEN)");
+                        "split_len = nbody_pair_once_split_len(n_total))");
         // the canonical summation: kSymGroups groups of ceil(n_splits / kSymGroups) splits; a context owns whole groups
         const int gs = std::max(1, (c->n_splits + kSymGroups - 1) / kSymGroups);
         const int split_lo = (int)(c->row_lo / c->split_len);

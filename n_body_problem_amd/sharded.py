@@ -93,7 +93,7 @@ class ShardedNBodySystem:
         self.world_size = dist.get_world_size(group) if self.distributed else 1
         self.num_bodies = int(num_bodies)
         if kernels_factory is None:
-            self.split_len = int(split_len) or (_system.PAIR_ONCE_SPLIT_LEN if force_mode == "pair_once" else
+            self.split_len = int(split_len) or (_system.pair_once_split_len(self.num_bodies) if force_mode == "pair_once" else
                                                 _system.default_split_len(self.num_bodies))
         else:
             if not split_len:

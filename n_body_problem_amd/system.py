@@ -25,7 +25,6 @@ from ._lib import NBodyError, check
 #: the reference's compile-time constants (kernel.cu:63, :66 and SURVEY.md 8a for the effective values)
 TIME_TICK = 0.008
 SOFTENING_VERSION3 = 1.0e-2  # cal_single_acclerate_without_mass_new: 0.1 pre-scale => eps^2 = 1e-4
-PAIR_ONCE_SPLIT_LEN = 2048       # NBODY_PAIR_ONCE_SPLIT_LEN, include/nbody.h
 SYM_GROUPS = 8                   # NBODY_SYM_GROUPS
 SOFTENING_VERSION1 = 1.0e-3  # cal_single_acclerate: eps^2 = EPSILON = 1e-6
 BLOCK_SIZE = 256
@@ -38,6 +37,11 @@ def _torch():
 
 def _ptr(t) -> ctypes.c_void_p:
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
+
+
+def pair_once_split_len(n_total: int) -> int:
+    """The split length to create a pair-once system with (a function of ``n_total`` only)."""
+    return int(_lib.load().nbody_pair_once_split_len(int(n_total)))
 
 
 def default_split_len(n_total: int) -> int:
@@ -219,7 +223,7 @@ class NBodySystem:
 
     def set_force_mode(self, mode: str) -> None:
         """``"one_sided"`` (default) or ``"symmetric"`` (the pair-once kernel; create the system with
-        ``split_len=PAIR_ONCE_SPLIT_LEN``).  A shard in the pair-once mode exchanges ``self.colparts`` once per step:
+        ``split_len=pair_once_split_len(n)``).  A shard in the pair-once mode exchanges ``self.colparts`` once per step:
         ``forces*`` -> ``sym_reduce()`` -> all-gather of ``sym_own_slice()`` -> ``update``."""
         code = {"one_sided": 0, "symmetric": 1, "pair_once": 1}[mode]
         check(self._lib.nbody_set_force_mode(self._ctx, code), self._ctx)

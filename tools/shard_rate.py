@@ -1,0 +1,51 @@
+"""One rank of P's share of a force pass, timed on one GPU (the other ranks' work is simply not done):
+python tools/shard_rate.py [--bodies N] [--world 8] [--rank 3] [--mode pair_once] [--split-len L ...]"""
+import argparse
+import torch
+import n_body_problem_amd as nb
+from n_body_problem_amd.sharded import pair_once_geometry, shard_geometry
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bodies", type=int, default=1 << 20)
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--rank", type=int, default=3)
+ap.add_argument("--mode", default="pair_once")
+ap.add_argument("--split-len", type=int, nargs="*", default=[2048, 1024])
+ap.add_argument("--two-streams", action="store_true")
+args = ap.parse_args()
+n = args.bodies
+pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
+for L in args.split_len:
+    L = L or nb.default_split_len(n)
+    geo = pair_once_geometry if args.mode == "pair_once" else shard_geometry
+    n_padded, chunk = geo(n, args.world, L)
+    assert n_padded == n
+    lo = args.rank * chunk
+    s = nb.NBodySystem(n, row_lo=lo, row_count=chunk, split_len=L)
+    s.set_force_mode(args.mode)
+    s.setParticlesPosition(pos)
+    s.setParticlesVelocity(vel[lo:lo + chunk])
+    side = torch.cuda.Stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    best = 1e9
+    for it in range(4):
+        torch.cuda.synchronize()
+        ev[0].record()
+        s.forces(lo, chunk, 1e-3)
+        if args.two_streams:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                s.forces_complement(lo, chunk, 1e-3)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            s.forces_complement(lo, chunk, 1e-3)
+        if args.mode == "pair_once":
+            s.sym_reduce()
+        s.update(0.0)
+        ev[1].record()
+        torch.cuda.synchronize()
+        if it:
+            best = min(best, ev[0].elapsed_time(ev[1]))
+    print(f"N={n} rank {args.rank}/{args.world} mode={args.mode} split_len={L} two_streams={args.two_streams}: "
+          f"{best:.3f} ms per step share -> x{args.world} ranks = {float(n) * n / best / 1e9:.3f}e12 interactions/s")
+    s.close()
