@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
     mode = "pair_once" if args.force_mode == "symmetric" else args.force_mode
+    if mode == "pair_once" and 8 % max(int(os.environ.get("WORLD_SIZE", "1")), 1):
+        log("the pair-once mode shards over 1, 2, 4 or 8 ranks: falling back to --force-mode one_sided")
+        mode = "one_sided"
 
     import torch
     import torch.distributed as dist

@@ -180,7 +180,7 @@ int nbody_sym_reduce(nbody_ctx *ctx);
 /* Per-particle softening: the reference loads a per-particle eps into velocities[4i+3]
  * (kernel.cu:223, 237) and no kernel ever reads it.  With d_eps (n_total floats on the device, borrowed until replaced;
  * NULL switches it off) every pair is softened by eps_ij^2 = softening^2 + eps_i^2 + eps_j^2 in the forces and in
- * nbody_energy.  One extra add per interaction, compiler-allocated kernel only; not available in the pair-once mode. */
+ * nbody_energy.  One extra add per interaction, compiler-scheduled kernels only (in both force modes). */
 int nbody_set_particle_softening(nbody_ctx *ctx, const float *d_eps);
 /* The same from n_total HOST floats, copied into a buffer the context owns (NULL switches it off). */
 int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);

@@ -548,8 +548,6 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
     const int first = (int)(col_lo / c->split_len);
     const int count = (int)((col_count + c->split_len - 1) / c->split_len);
     if (c->force_mode == NBODY_FORCE_SYMMETRIC) {
-        if (c->eps_pp)
-            return fail(c, NBODY_ERR_INVALID, std::string(who) + ": the pair-once mode has no per-particle softening");
         // this context's tiles with a column split in the range asked for (cached per range)
         const int S = c->n_splits, L = (int)c->split_len;
         const int own_lo = (int)(c->row_lo / L), own_hi = (int)((c->row_lo + c->row_count + L - 1) / L);
@@ -593,6 +591,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.row_lo = (int)c->row_lo;
         sa.row_count = (int)c->row_count;
         sa.eps2 = softening * softening;
+        sa.eps_pp = c->eps_pp;
         HIP_TRY(c, hipSetDevice(c->device));
         {
             TimedLaunch t(c, &c->ev_force);  // the dominant kernel alone, so that the time is rocprofv3's for it

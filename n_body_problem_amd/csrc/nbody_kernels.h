@@ -56,6 +56,7 @@ struct SymArgs {
     int split_len;         // 256 <= split_len <= 4096, multiple of 256
     int row_lo, row_count; // the context's own rows (whole splits)
     float eps2;
+    const float *eps_pp;   // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
 };
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);       // the tiles (R != C)
 hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream);  // the diagonal tiles

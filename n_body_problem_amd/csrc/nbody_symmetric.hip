@@ -21,8 +21,9 @@
 //   * small workgroups and <= 28 KiB of LDS (split_len 2048) put 5 workgroups = 5 waves per SIMD on a CU, enough for
 //     the idle-gap schedule of force_kernel_r4 to hide each wave's slow window after its
 //     v_rsq_f32 batch;
-//   * diagonal tiles (I == J) are a separate, compiler-scheduled kernel that visits every (row, column) combination
-//     and keeps the pairs with row index < column index (1/n_splits of the work).
+//   * diagonal tiles (R == C) are a separate, compiler-scheduled kernel that visits every (row, column) combination
+//     and keeps the pairs with row index < column index (1/n_splits of the work); the same kernel, without the mask,
+//     computes every tile when per-particle softening is on.
 //
 // Per unordered pair: 3 sub, 3 fma, rsq, 4 mul, 6 fma = 16 VALU + 1 transcendental (+ 3 DPP moves and 2 address
 // operations per 64 x 4 pairs) against 2 x (12 + 1) for the two ordered interactions it replaces.
@@ -230,18 +231,24 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
             out[colbase + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
-// ---- diagonal tiles (I == J): rows and columns are the same bodies, keep row < column (drops the self pair too) ----
-template <bool GUARD>
-__global__ __launch_bounds__(kSymThreads) void force_sym_diag_kernel(SymArgs a)
+// ---- the compiler-scheduled tile kernel: diagonal tiles, and every tile under per-particle softening ---------------
+// DIAG: rows and columns are the same bodies; every (row, column) combination is visited and the pairs with row index
+// < column index are kept (drops the self pair too); both sides end in P_row[B].  PPS: eps_ij^2 = eps^2 + eps_i^2 +
+// eps_j^2 (symmetric in the pair, so it fits the pair-once scheme): one extra add per pair and a 64-float LDS stage
+// of the group's eps_j^2 per wave.  Same data flow and summation order as the hand-scheduled kernel above.
+template <bool DIAG, bool GUARD, bool PPS>
+__global__ __launch_bounds__(kSymThreads) void force_sym_general_kernel(SymArgs a)
 {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int L = a.split_len, G = L / 64;
     const SymLds lds = sym_lds(smem, L);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int split = a.diag_tiles[blockIdx.x].x;
-    const int base = split * L;
+    float *estage = lds.sz + L + wave * 64;
+    const int2 t = DIAG ? a.diag_tiles[blockIdx.x] : a.tiles[blockIdx.x];
+    const int rowbase = t.x * L, colbase = t.y * L;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
+    const int row_hi = min(a.row_lo + a.row_count, a.n_total);
     float eps2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(eps2) : "s"(a.eps2));
 
@@ -250,44 +257,56 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_diag_kernel(SymArgs a)
     __syncthreads();
 
     for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
-        float x[kSymRows], y[kSymRows], z[kSymRows], m[kSymRows], ax[kSymRows], ay[kSymRows], az[kSymRows];
+        float x[kSymRows], y[kSymRows], z[kSymRows], m[kSymRows], ax[kSymRows], ay[kSymRows], az[kSymRows], er[kSymRows];
         int rl[kSymRows];  // row index inside the split, or -1
 #pragma unroll
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             float4 p = zero4;
+            float e = 0.f;
             rl[k] = -1;
-            if (r < L && base + r < a.n_total) {
-                p = a.pos[base + r];
+            if (r < L && rowbase + r < row_hi) {
+                p = a.pos[rowbase + r];
+                if (PPS)
+                    e = a.eps_pp[rowbase + r];
                 rl[k] = r;
             }
             x[k] = p.x; y[k] = p.y; z[k] = p.z; m[k] = p.w;
+            er[k] = __builtin_fmaf(e, e, eps2);  // eps^2 + eps_i^2
             ax[k] = ay[k] = az[k] = 0.f;
         }
         for (int g = 0; g < G; ++g) {
             const int cg = sym_group(g, wave, spacing, G);
-            const int gc = base + cg * 64 + lane;
+            const int gc = colbase + cg * 64 + lane;
             float4 c = zero4;
-            if (gc < a.n_total)
+            float ec = 0.f;
+            if (gc < a.n_total) {
                 c = a.pos[gc];
+                if (PPS)
+                    ec = a.eps_pp[gc];
+            }
             lds.stage[lane] = c;
+            if (PPS)
+                estage[lane] = ec * ec;
             float cx = 0.f, cy = 0.f, cz = 0.f;
 #pragma unroll 4
             for (int s = 0; s < 64; ++s) {
                 const int cl = (lane + s) & 63;
                 const float4 pj = lds.stage[cl];
+                const float ej = PPS ? estage[cl] : 0.f;
                 const int col = cg * 64 + cl;
 #pragma unroll
                 for (int k = 0; k < kSymRows; ++k) {
                     const float dx = pj.x - x[k], dy = pj.y - y[k], dz = pj.z - z[k];
-                    float r2 = __builtin_fmaf(dx, dx, eps2);
+                    float r2 = __builtin_fmaf(dx, dx, PPS ? er[k] + ej : eps2);
                     r2 = __builtin_fmaf(dy, dy, r2);
                     r2 = __builtin_fmaf(dz, dz, r2);
                     if (GUARD)
                         r2 = __builtin_fmaxf(r2, 1.0e-24f);
                     const float inv = __builtin_amdgcn_rsqf(r2);
                     float inv3 = inv * (inv * inv);
-                    inv3 = (rl[k] >= 0 && rl[k] < col) ? inv3 : 0.f;
+                    if (DIAG)
+                        inv3 = (rl[k] >= 0 && rl[k] < col) ? inv3 : 0.f;
                     const float sr = pj.w * inv3, sc = m[k] * inv3;
                     ax[k] = __builtin_fmaf(dx, sr, ax[k]);
                     ay[k] = __builtin_fmaf(dy, sr, ay[k]);
@@ -309,24 +328,36 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_diag_kernel(SymArgs a)
                 __syncthreads();
         }
         __syncthreads();
-        // row sums of this pass join the column sums of the same bodies
+        if (DIAG) {  // row sums of this pass join the column sums of the same bodies
 #pragma unroll
-        for (int k = 0; k < kSymRows; ++k)
-            if (rl[k] >= 0) {
-                lds.sx[rl[k]] += ax[k];
-                lds.sy[rl[k]] += ay[k];
-                lds.sz[rl[k]] += az[k];
-            }
-        __syncthreads();
+            for (int k = 0; k < kSymRows; ++k)
+                if (rl[k] >= 0) {
+                    lds.sx[rl[k]] += ax[k];
+                    lds.sy[rl[k]] += ay[k];
+                    lds.sz[rl[k]] += az[k];
+                }
+            __syncthreads();
+        } else {
+            float4 *out = a.row_partials + (size_t)t.y * a.row_count;  // P_row[C][row]
+#pragma unroll
+            for (int k = 0; k < kSymRows; ++k)
+                if (rl[k] >= 0)
+                    out[rowbase + rl[k] - a.row_lo] = make_float4(ax[k], ay[k], az[k], 0.f);
+        }
     }
 
-    float4 *out = a.row_partials + (size_t)split * a.row_count;  // both sides of the split: P_row[B][b]
+    // DIAG: both sides of the split, P_row[B][b]; else the column sums, P_col[R][column]
+    float4 *out = DIAG ? a.row_partials + (size_t)t.x * a.row_count : a.col_partials + (size_t)(t.x - a.row_lo / L) * a.n_total;
     for (int c = tid; c < L; c += kSymThreads)
-        if (base + c < a.n_total)
-            out[base + c - a.row_lo] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
+        if (colbase + c < a.n_total)
+            out[DIAG ? colbase + c - a.row_lo : colbase + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
-size_t symmetric_lds_bytes(int split_len) { return (size_t)split_len * 12 + (size_t)kSymStageFloats * sizeof(float); }
+// the column-group stage, three column-sum arrays, and the per-wave eps_j^2 stage of the per-particle-softening variant
+size_t symmetric_lds_bytes(int split_len)
+{
+    return (size_t)kSymStageFloats * sizeof(float) + (size_t)split_len * 12 + (size_t)kSymWaves * 64 * sizeof(float);
+}
 
 template <typename K>
 static hipError_t sym_launch(K kernel, int blocks, size_t lds, const SymArgs &a, hipStream_t stream)
@@ -344,6 +375,9 @@ static hipError_t sym_launch(K kernel, int blocks, size_t lds, const SymArgs &a,
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
 {
     const size_t lds = symmetric_lds_bytes(a.split_len);
+    if (a.eps_pp)  // per-particle softening: the compiler-scheduled kernel (a particle may have eps = 0: keep the guard at eps = 0)
+        return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<false, false, true>, a.n_tiles, lds, a, stream)
+                            : sym_launch(&force_sym_general_kernel<false, true, true>, a.n_tiles, lds, a, stream);
     return a.eps2 > 0.f ? sym_launch(&force_sym_kernel<false>, a.n_tiles, lds, a, stream)
                         : sym_launch(&force_sym_kernel<true>, a.n_tiles, lds, a, stream);
 }
@@ -351,8 +385,11 @@ hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
 hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream)
 {
     const size_t lds = symmetric_lds_bytes(a.split_len);
-    return a.eps2 > 0.f ? sym_launch(&force_sym_diag_kernel<false>, a.n_diag, lds, a, stream)
-                        : sym_launch(&force_sym_diag_kernel<true>, a.n_diag, lds, a, stream);
+    if (a.eps_pp)
+        return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<true, false, true>, a.n_diag, lds, a, stream)
+                            : sym_launch(&force_sym_general_kernel<true, true, true>, a.n_diag, lds, a, stream);
+    return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<true, false, false>, a.n_diag, lds, a, stream)
+                        : sym_launch(&force_sym_general_kernel<true, true, false>, a.n_diag, lds, a, stream);
 }
 
 // ---- the canonical summation of the pair-once partial sums (HBM-bound, O(N n_splits)) ------------------------------

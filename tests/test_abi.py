@@ -51,6 +51,14 @@ def test_default_split_len_is_tile_aligned_and_sharding_independent(lib):
     assert lib.nbody_default_split_len(65536) == 512 and lib.nbody_default_split_len(20000) == 256
 
 
+def test_pair_once_split_len_depends_on_the_body_count_only(lib):
+    f = lib.nbody_pair_once_split_len
+    assert [f(n) for n in (0, 1, 20000, 1 << 17, 1 << 20)] == [1024] * 5          # the kernel's rows per pass
+    assert f(1 << 21) == 2048 and f(1 << 22) == 4096 and f(1 << 24) == 4096       # then bounded partial sums
+    for n in (1 << 20, 1 << 21, 1 << 22):
+        assert 2 * 16 * n * (n // f(n)) <= 140e9                                  # both arrays, all contexts together
+
+
 def test_argument_errors_come_before_any_device_work(lib):
     ctx = ctypes.c_void_p(None)
     assert lib.nbody_create(None, 0, 16) == -1

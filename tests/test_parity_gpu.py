@@ -488,7 +488,7 @@ def test_per_particle_softening_matches_oracle(nb, oracle_mod, n, eps):
     assert np.abs(uni - glob).max() / np.abs(glob).max() <= TOL
 
 
-def test_per_particle_softening_shards_energy_and_pair_once_refusal(nb, oracle_mod):
+def test_per_particle_softening_shards_and_energy(nb, oracle_mod):
     n, split_len = 6000, 512
     pos, vel = nb.plummer(n, seed=42)
     eps_pp = np.random.default_rng(42).uniform(0.0, 0.03, n).astype(np.float32)
@@ -513,9 +513,55 @@ def test_per_particle_softening_shards_energy_and_pair_once_refusal(nb, oracle_m
         e_plain = s.energy(1e-3)
     assert np.isclose(e[1], oracle_mod.potential_pps(pos, eps_pp, 1e-3), rtol=1e-6)
     assert np.allclose(e_plain, oracle_mod.energy(pos, vel, 1e-3), rtol=1e-6)
-    with nb.NBodySystem(16384, split_len=1024) as s:
+
+
+@pytest.mark.parametrize("eps", [1e-3, 0.0])
+def test_per_particle_softening_in_the_pair_once_mode(nb, oracle_mod, eps):
+    """eps_ij^2 is symmetric in the pair, so the pair-once kernels take it too: against the fp64 oracle, against the
+    one-sided kernel, and bit-identical when the rows are shared by two contexts."""
+    n, L = 12000, 1024                                # 12 splits (the last one ragged), 8 groups of 2
+    pos, _ = nb.plummer(n, seed=43)
+    eps_pp = np.random.default_rng(43).uniform(0.0, 0.05, n).astype(np.float32)
+    eps_pp[::5] = 0.0
+    pos[21] = pos[20]                                 # a coincident pair, inside one tile
+    pos[5000] = pos[100]                              # and one across tiles
+    sym = pps_accel_mode(nb, pos, eps_pp, eps, "symmetric", L)
+    one = pps_accel_mode(nb, pos, eps_pp, eps, "one_sided", L)
+    want = oracle_mod.accel_f64_pps(pos, eps_pp, eps)
+    assert np.isfinite(sym).all()
+    assert np.abs(sym - want).max() / np.abs(want).max() <= TOL
+    assert np.linalg.norm(sym - one) / np.linalg.norm(one) < 1e-6
+    zero = pps_accel_mode(nb, pos, np.zeros(n, np.float32), 1e-3, "symmetric", L)
+    plain = sym_run(nb, pos, np.zeros_like(pos), 1.0, 1e-3, 1, "symmetric", L)[1][:, :3]
+    assert np.abs(zero - plain).max() / np.abs(plain).max() < 1e-6    # another kernel, the same sums to rounding
+    # two contexts sharing the rows (groups 0-3 and 4-7 = splits 0-7 and 8-11), column sums copied by hand
+    import torch
+    half = 8 * L
+    a = nb.NBodySystem(n, row_lo=0, row_count=half, split_len=L)
+    b = nb.NBodySystem(n, row_lo=half, row_count=n - half, split_len=L)
+    for s in (a, b):
         s.set_force_mode("symmetric")
-        s.set_particle_softening(np.zeros(16384, np.float32))
-        s.setParticlesPosition(nb.plummer(16384, seed=1)[0])
-        with pytest.raises(nb.NBodyError):
-            s.step(1e-3, 1e-3)
+        s.set_particle_softening(eps_pp)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(np.zeros((s.row_count, 4), np.float32))
+        s.forces(0, n, eps)
+        s.sym_reduce()
+    a.colparts[4:8].copy_(b.colparts[4:8])
+    b.colparts[0:4].copy_(a.colparts[0:4])
+    for s in (a, b):
+        s.update(1.0)
+    got = np.concatenate([a.download()[1][:, :3], b.download()[1][:, :3]])
+    a.close()
+    b.close()
+    assert np.array_equal(got, sym)
+
+
+def pps_accel_mode(nb, pos, eps_pp, eps, mode, split_len):
+    n = pos.shape[0]
+    with nb.NBodySystem(n, split_len=split_len) as s:
+        s.set_force_mode(mode)
+        s.set_particle_softening(eps_pp)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(np.zeros_like(pos))
+        s.step(1.0, eps)
+        return s.download()[1][:, :3]
