@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -555,15 +556,34 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         auto it = c->sym_tiles.find(key);
         if (it == c->sym_tiles.end()) {
             std::vector<int2> tiles, diag;
+            auto selected = [&](int C) { return (C >= first && C < first + count) != complement; };
             for (int R = own_lo; R < own_hi; ++R)
-                for (int C = 0; C < S; ++C) {
-                    if ((C >= first && C < first + count) == complement)
-                        continue;
-                    if (C == R)
-                        diag.push_back(make_int2(R, R));
-                    else if (sym_rows_side(R, C, S))
-                        tiles.push_back(make_int2(R, C));
-                }
+                if (selected(R))
+                    diag.push_back(make_int2(R, R));
+            // Launch order = L2 locality (speed only; every tile has its own outputs).  The tile of row split R and ring
+            // distance d has column split (R + d) mod S.  Blocks of 8 row splits x 8 distances touch 23 splits' bodies
+            // instead of 128; workgroups are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md), so block k's tiles
+            // take the launch slots congruent to k mod 8 and meet in one XCD's L2.
+            static const bool blocked = !(getenv("NBODY_SYM_TILE_ORDER") && atoi(getenv("NBODY_SYM_TILE_ORDER")) == 0);
+            std::vector<std::vector<int2>> per_xcd(blocked ? 8 : 1);
+            int k = 0;
+            const int B = blocked ? 8 : S;
+            for (int Rb = own_lo; Rb < own_hi; Rb += B)
+                for (int db = 1; db <= S / 2; db += B, ++k)
+                    for (int R = Rb; R < std::min(Rb + B, own_hi); ++R)
+                        for (int d = db; d < std::min(db + B, S / 2 + 1); ++d) {
+                            const int C = (R + d) % S;
+                            if (selected(C) && sym_rows_side(R, C, S))
+                                per_xcd[(size_t)k % per_xcd.size()].push_back(make_int2(R, C));
+                        }
+            for (size_t j = 0, more = 1; more; ++j) {
+                more = 0;
+                for (auto &seq : per_xcd)
+                    if (j < seq.size()) {
+                        tiles.push_back(seq[j]);
+                        more = 1;
+                    }
+            }
             nbody_ctx::SymTiles t;
             HIP_TRY(c, hipSetDevice(c->device));
             if (!tiles.empty()) {
