@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--force-mode", default="pair_once", choices=["pair_once", "one_sided"])
     ap.add_argument("--integrator", default="kick_drift", choices=["kick_drift", "kdk"])
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "ring"])
+    ap.add_argument("--split-len", type=int, default=0, help="0 = the mode's default for this body count")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -45,7 +46,8 @@ def main():
             dist.init_process_group("gloo")
     n = args.bodies
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[5])
-    s = ShardedNBodySystem(n, device=local, exchange=args.exchange, force_mode=args.force_mode, integrator=args.integrator)
+    s = ShardedNBodySystem(n, device=local, exchange=args.exchange, force_mode=args.force_mode, integrator=args.integrator,
+                           split_len=args.split_len)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel)
     del pos, vel
