@@ -29,7 +29,7 @@ struct nbody_ctx {
     // pair-once mode (nbody_symmetric.hip)
     struct SymTiles { int2 *tiles = nullptr; int n = 0; int2 *diag = nullptr; int n_diag = 0; };
     std::map<std::tuple<int, int, bool>, SymTiles> sym_tiles;  // per column range asked for: its (R, C) tiles
-    float4 *col_partials = nullptr;  // [own splits][n_total]
+    float4 *col_partials = nullptr;  // [own splits][n_splits / 2][split_len], see SymArgs
     float4 *colparts = nullptr;      // [kSymGroups][n_total] in use: the caller's (nbody_sym_set_colparts) or colparts_own
     float4 *colparts_own = nullptr;
     float4 *sym_acc = nullptr;       // [row_count]: the summed accelerations the update kernels read as one split
@@ -38,7 +38,9 @@ struct nbody_ctx {
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream or the caller's)
-    float4 *partials = nullptr;    // [n_splits][row_count]  (the reference's gravity_sum_array, kernel.cu:1148)
+    float4 *partials = nullptr;    // [n_splits][row_count]  (the reference's gravity_sum_array, kernel.cu:1148);
+                                   // pair-once mode: [n_splits / 2 + 1][row_count].  Allocated at the first force call.
+    size_t partials_entries = 0;
     float4 *pos = nullptr;         // owned position buffer (n_total), optional
     float4 *vel = nullptr;         // owned velocity buffer (row_count), optional
     double *reduce_dev = nullptr;  // per-block partials of the diagnostics kernels
@@ -109,10 +111,12 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
 {
     // 1024 = the pair-once kernel's rows per pass (4 waves x 64 lanes x 4 rows): shorter splits idle waves, longer ones
     // coarsen the grid (at N = 2^20 one of 8 ranks measured 24.4 ms per step with 1024, 25.8 with 2048, 46.9 with 512;
-    // N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms).  The partial sums cost n_total^2 / split_len x 16 B twice.
-    const double need = (double)n_total * (double)n_total / 2.5e9;
+    // N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms; 4096 leaves 3 workgroups per CU: 441 against 392 ms for one of 8 ranks
+    // at N = 2^22).  The two partial-sum arrays together hold n_total^2 / split_len x 16 B: 17 GB at N = 2^20, and the
+    // length doubles where that would pass 150 GB (137 GB at N = 2^22 with 2048: one GPU can still hold it).
+    const double pairs16 = 16.0 * (double)n_total * (double)n_total;
     int64_t len = 1024;
-    while (len < 4096 && (double)len < need)
+    while (len < 4096 && pairs16 / (double)len > 150e9)
         len *= 2;
     return len;
 }
@@ -172,9 +176,6 @@ int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row
     };
     guard(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
     c->stream = c->own_stream;
-    size_t part_bytes = sizeof(float4) * (size_t)c->n_splits * (size_t)row_count;
-    if (rc == NBODY_OK && part_bytes)
-        guard(hipMalloc((void **)&c->partials, part_bytes), "hipMalloc(partials)");
     size_t red = (size_t)std::max(1, energy_blocks((int)row_count)) * 4;
     if (rc == NBODY_OK)
         guard(hipMalloc((void **)&c->reduce_dev, red * sizeof(double)), "hipMalloc(reduce)");
@@ -396,8 +397,11 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         c->group_lo = split_lo / gs;
         c->group_count = c->row_count ? (split_hi + gs - 1) / gs - c->group_lo : 0;
         HIP_TRY(c, hipSetDevice(c->device));
-        if (!c->col_partials && c->row_count)
-            HIP_TRY(c, hipMalloc((void **)&c->col_partials, sizeof(float4) * (size_t)(split_hi - split_lo) * (size_t)c->n_total));
+        if (!c->col_partials && c->row_count && c->n_splits > 1 &&
+            hipMalloc((void **)&c->col_partials, sizeof(float4) * (size_t)(split_hi - split_lo) * (size_t)(c->n_splits / 2) *
+                                                     (size_t)c->split_len) != hipSuccess)
+            return fail(c, NBODY_ERR_ALLOC, "nbody_set_force_mode: hipMalloc of the column-side partial sums failed (a longer "
+                                            "split_len needs less)");
         if (!c->sym_acc && c->row_count)
             HIP_TRY(c, hipMalloc((void **)&c->sym_acc, sizeof(float4) * (size_t)c->row_count));
         if (!c->colparts) {
@@ -534,6 +538,27 @@ static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
     return 1;
 }
 
+// The partial-sum array of the current force mode (a mode switch may need a larger one).
+static int ensure_partials(nbody_ctx *c)
+{
+    const size_t slots = c->force_mode == NBODY_FORCE_SYMMETRIC ? (size_t)c->n_splits / 2 + 1 : (size_t)c->n_splits;
+    const size_t entries = slots * (size_t)c->row_count;
+    if (entries <= c->partials_entries)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->partials) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->partials);
+        c->partials = nullptr;
+        c->partials_entries = 0;
+    }
+    if (hipMalloc((void **)&c->partials, sizeof(float4) * entries) != hipSuccess)
+        return fail(c, NBODY_ERR_ALLOC, "partial sums: hipMalloc of " + std::to_string(sizeof(float4) * entries >> 20) +
+                                            " MiB failed (a longer split_len needs less)");
+    c->partials_entries = entries;
+    return NBODY_OK;
+}
+
 static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t col_count, float softening,
                        bool complement, const char *who)
 {
@@ -546,6 +571,11 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return fail(c, NBODY_ERR_INVALID, std::string(who) + ": column range must be split-aligned and inside [0,n_total]");
     if (c->row_count == 0 || c->n_total == 0)
         return NBODY_OK;
+    {
+        int rc = ensure_partials(c);
+        if (rc != NBODY_OK)
+            return rc;
+    }
     const int first = (int)(col_lo / c->split_len);
     const int count = (int)((col_count + c->split_len - 1) / c->split_len);
     if (c->force_mode == NBODY_FORCE_SYMMETRIC) {

@@ -46,8 +46,10 @@ __host__ __device__ inline bool sym_rows_side(int R, int C, int S)
 
 struct SymArgs {
     const float4 *pos;     // all n_total bodies
-    float4 *row_partials;  // [n_splits][row_count]: P_row[C][b] = force on own body b from the bodies of split C
-    float4 *col_partials;  // [own splits][n_total]: P_col[R][c] = force on body c (any rank's) from own split R
+    // Both arrays are indexed by the ring distance d = (C - R) mod S of the tile, 0 <= d <= S/2 (0: the diagonal), so
+    // they hold exactly the partial sums that exist:
+    float4 *row_partials;  // [S/2 + 1][row_count]: P_row[d][b] = force on own body b (split R) from the bodies of split R + d
+    float4 *col_partials;  // [own splits][S/2][split_len]: P_col[R][d - 1][i] = force on body i of split R + d from own split R
     const int2 *tiles;     // n_tiles pairs (R, C), R an own split, R != C
     int n_tiles;
     const int2 *diag_tiles;  // n_diag pairs (B, B), own splits: every pair inside the split once, both sides

@@ -6,9 +6,9 @@
 // make the result order-dependent.  This kernel keeps the idea and drops the atomics:
 //
 //   * tiles are pairs of splits (R, C), split_len bodies each; ONE 256-thread workgroup (4 wave64) per tile, so every
-//     partial sum is produced by exactly one workgroup:
-//        rows b in R, columns c in C:  P_row[C][b] = sum_c m_c f(b,c)   (row side, registers)
-//                                      P_col[R][c] = -sum_b m_b f(b,c)  (column side, LDS)
+//     partial sum is produced by exactly one workgroup (d = (C - R) mod n_splits, the tile's ring distance):
+//        rows b in R, columns c in C:  P_row[d][b]    = sum_c m_c f(b,c)   (row side, registers)
+//                                      P_col[R][d][c] = -sum_b m_b f(b,c)  (column side, LDS)
 //     each unordered pair {R, C} is one tile, with the side sym_rows_side() names as rows -- so that the tiles of a
 //     context that owns the rows of some splits are exactly the ones with R among them (sharding over GPUs: the
 //     P_col of remote bodies are summed per group of splits, exchanged once per step and added in a fixed order);
@@ -112,6 +112,18 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     "s_cbranch_scc1 1b\n\t"                                                                                      \
     "s_waitcnt lgkmcnt(0)\n"
 
+// ring distance of the tile (R, C): its slot in the partial-sum arrays
+__device__ __forceinline__ int sym_distance(int R, int C, int S)
+{
+    const int d = C - R;
+    return d < 0 ? d + S : d;
+}
+// P_col[R_local][d - 1][0 .. split_len)
+__device__ __forceinline__ float4 *sym_col_slot(float4 *col_partials, int r_local, int d, int S, int L)
+{
+    return col_partials + ((size_t)r_local * (size_t)(S / 2) + (size_t)(d - 1)) * (size_t)L;
+}
+
 struct SymLds {
     float4 *stage;  // this wave's 64-body group
     float *sx, *sy, *sz;
@@ -151,6 +163,7 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
     const int row_hi = min(a.row_lo + a.row_count, a.n_total);
+    const int S = (a.n_total + L - 1) / L;
 
     for (int c = tid; c < L; c += kSymThreads)
         lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
         }
         __syncthreads();
 
-        float4 *out = a.row_partials + (size_t)t.y * a.row_count;  // row sums of this pass: P_row[C][row]
+        float4 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // row sums: P_row[d][row]
 #pragma unroll
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
@@ -225,10 +238,10 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
         }
     }
 
-    float4 *out = a.col_partials + (size_t)(t.x - a.row_lo / L) * a.n_total;  // column sums: P_col[R][column]
+    float4 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);  // P_col[R][d-1][.]
     for (int c = tid; c < L; c += kSymThreads)
         if (colbase + c < a.n_total)
-            out[colbase + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
+            out[c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
 // ---- the compiler-scheduled tile kernel: diagonal tiles, and every tile under per-particle softening ---------------
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_general_kernel(SymArgs 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
     const int row_hi = min(a.row_lo + a.row_count, a.n_total);
+    const int S = (a.n_total + L - 1) / L;
     float eps2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(eps2) : "s"(a.eps2));
 
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_general_kernel(SymArgs 
                 }
             __syncthreads();
         } else {
-            float4 *out = a.row_partials + (size_t)t.y * a.row_count;  // P_row[C][row]
+            float4 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // P_row[d][row]
 #pragma unroll
             for (int k = 0; k < kSymRows; ++k)
                 if (rl[k] >= 0)
@@ -346,11 +360,12 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_general_kernel(SymArgs 
         }
     }
 
-    // DIAG: both sides of the split, P_row[B][b]; else the column sums, P_col[R][column]
-    float4 *out = DIAG ? a.row_partials + (size_t)t.x * a.row_count : a.col_partials + (size_t)(t.x - a.row_lo / L) * a.n_total;
+    // DIAG: both sides of the split, P_row[0][b]; else the column sums, P_col[R][d-1][.]
+    float4 *out = DIAG ? a.row_partials + (rowbase - a.row_lo)
+                       : sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);
     for (int c = tid; c < L; c += kSymThreads)
         if (colbase + c < a.n_total)
-            out[DIAG ? colbase + c - a.row_lo : colbase + c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
+            out[c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
 // the column-group stage, three column-sum arrays, and the per-wave eps_j^2 stage of the per-particle-softening variant
@@ -406,12 +421,13 @@ __global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float4 *col_p
     const int g = group_lo + blockIdx.y;
     if (c >= n_total)
         return;
-    const int C = c / split_len;  // uniform in the workgroup (split_len is a multiple of kTile)
+    const int C = c / split_len, off = c - C * split_len;  // C is uniform in the workgroup (split_len % kTile == 0)
     const int r0 = g * group_splits, r1 = min(r0 + group_splits, n_splits);
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int R = r0; R < r1; ++R)
         if (sym_rows_side(R, C, n_splits)) {
-            const float4 v = col_partials[(size_t)(R - split_lo) * n_total + c];
+            const float4 v = sym_col_slot(const_cast<float4 *>(col_partials), R - split_lo, sym_distance(R, C, n_splits),
+                                          n_splits, split_len)[off];
             sx += v.x;
             sy += v.y;
             sz += v.z;
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float4 *row_p
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int C = c0; C < c1; ++C)
             if (C == B || sym_rows_side(B, C, n_splits)) {
-                const float4 v = row_partials[(size_t)C * row_count + b];
+                const float4 v = row_partials[(size_t)sym_distance(B, C, n_splits) * row_count + b];
                 sx += v.x;
                 sy += v.y;
                 sz += v.z;

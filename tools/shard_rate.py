@@ -16,7 +16,7 @@ args = ap.parse_args()
 n = args.bodies
 pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
 for L in args.split_len:
-    L = L or nb.default_split_len(n)
+    L = L or (nb.pair_once_split_len(n) if args.mode == "pair_once" else nb.default_split_len(n))
     geo = pair_once_geometry if args.mode == "pair_once" else shard_geometry
     n_padded, chunk = geo(n, args.world, L)
     assert n_padded == n
