@@ -172,6 +172,39 @@ def sym_step(gap, rotate=True, addr=True, post_order="row", halves=False):
     return body
 
 
+def sym_two_steps(gap, gap2=0):
+    """Two steps' eight pairs in one v_rsq_f32 batch (arithmetic only): second column in v6..v9, second temp set v72..v87."""
+    pre, rsq, post = [], [], []
+    for u, (px, py, pz, pm) in enumerate((("v2", "v3", "v4", "v5"), ("v6", "v7", "v8", "v9"))):
+        for k in range(4):
+            X, Y, Z, M = (f"v{12+4*k+c}" for c in range(4))
+            base = 28 + 4 * k if u == 0 else 72 + 4 * k
+            D0, D1, D2, Rr = (f"v{base+c}" for c in range(4))
+            AZ, AX, AY = (f"v{52+4*k+c}" for c in range(3))
+            Q, T, SC = ("v44", "v46", "v47") if k % 2 == 0 else ("v48", "v50", "v51")
+            pre += [f"v_sub_f32_e32 {D0}, {px}, {X}", f"v_sub_f32_e32 {D1}, {py}, {Y}", f"v_sub_f32_e32 {D2}, {pz}, {Z}",
+                    f"v_fma_f32 {Rr}, {D0}, {D0}, v11", f"v_fmac_f32_e32 {Rr}, {D1}, {D1}", f"v_fmac_f32_e32 {Rr}, {D2}, {D2}"]
+            rsq += [f"v_rsq_f32_e32 {Rr}, {Rr}"]
+            post += [f"v_mul_f32_e32 {Q}, {Rr}, {Rr}", f"v_mul_f32_e32 {T}, {Rr}, {Q}", f"v_mul_f32_e32 {SC}, {M}, {T}",
+                     f"v_mul_f32_e32 {Rr}, {pm}, {T}", f"v_fmac_f32_e32 {AX}, {D0}, {Rr}", f"v_fmac_f32_e32 {AY}, {D1}, {Rr}",
+                     f"v_fmac_f32_e32 {AZ}, {D2}, {Rr}", f"v_fmac_f32_e32 v45, {D0}, {SC}", f"v_fmac_f32_e32 v68, {D1}, {SC}",
+                     f"v_fmac_f32_e32 v49, {D2}, {SC}"]
+            if u == 0 and k == 3 and gap2:
+                post += nops(gap2)
+    return pre + rsq + nops(gap) + post
+
+
+class SymAlloc2(SymAlloc):
+    nreg = 112
+    R, U = 4, 2
+
+
+for gap in (0, 12, 24, 40):
+    add(f"sym2_g{gap}", f"pair-once, TWO steps per rsq batch (8 pairs), arithmetic only, gap {gap}, 112 regs", SymAlloc2(),
+        sym_two_steps(gap), 1)
+al2 = SymAlloc2(); al2.nreg = 96
+add("sym2_g24_r96", "pair-once, two steps per rsq batch, gap 24, 96 regs (hypothetical)", al2, sym_two_steps(24), 1)
+
 for nreg, tag in ((96, "5 waves"), (128, "4 waves"), (64, "8 waves")):
     for gap in (0, 12, 24):
         al = SymAlloc()
