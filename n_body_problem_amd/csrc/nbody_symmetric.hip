@@ -222,10 +222,8 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
             lds.sx[cg * 64 + lane] -= cx;
             lds.sy[cg * 64 + lane] -= cy;
             lds.sz[cg * 64 + lane] -= cz;
-#ifndef NB_SYM_NOBARRIER  // (timing experiments only)
             if ((g + 1) % spacing == 0)
                 __syncthreads();
-#endif
         }
         __syncthreads();
 
