@@ -194,6 +194,54 @@ def sym_two_steps(gap, gap2=0):
     return pre + rsq + nops(gap) + post
 
 
+def sym_step8(gap, rotate="bpermute", addr=True):
+    """8 rows per lane: two 4-row sub-batches share the column body, the address update and the three permutes.
+    Rows 4..7 at v72..v87, their sums at v88..v103 (same bank pattern as rows 0..3)."""
+    px, py, pz, pm = "v2", "v3", "v4", "v5"
+    body = []
+    if addr:
+        body += ["v_add_u32_e32 v1, 16, v1", "v_and_or_b32 v0, v1, v55, v10"]
+    if rotate == "bpermute":
+        body += ["s_waitcnt lgkmcnt(3)"]
+    for half in range(2):
+        pre, rsq, post = [], [], []
+        for k in range(4):
+            rb = 12 + 4 * k if half == 0 else 72 + 4 * k
+            sb = 52 + 4 * k if half == 0 else 88 + 4 * k
+            X, Y, Z, M = (f"v{rb+c}" for c in range(4))
+            D0, D1, D2, Rr = (f"v{28+4*k+c}" for c in range(4))
+            AZ, AX, AY = (f"v{sb+c}" for c in range(3))
+            Q, T, SC = ("v44", "v46", "v47") if k % 2 == 0 else ("v48", "v50", "v51")
+            pre += [f"v_sub_f32_e32 {D0}, {px}, {X}", f"v_sub_f32_e32 {D1}, {py}, {Y}", f"v_sub_f32_e32 {D2}, {pz}, {Z}",
+                    f"v_fma_f32 {Rr}, {D0}, {D0}, v11", f"v_fmac_f32_e32 {Rr}, {D1}, {D1}", f"v_fmac_f32_e32 {Rr}, {D2}, {D2}"]
+            rsq += [f"v_rsq_f32_e32 {Rr}, {Rr}"]
+            post += [f"v_mul_f32_e32 {Q}, {Rr}, {Rr}", f"v_mul_f32_e32 {T}, {Rr}, {Q}", f"v_mul_f32_e32 {SC}, {M}, {T}",
+                     f"v_mul_f32_e32 {Rr}, {pm}, {T}", f"v_fmac_f32_e32 {AX}, {D0}, {Rr}", f"v_fmac_f32_e32 {AY}, {D1}, {Rr}",
+                     f"v_fmac_f32_e32 {AZ}, {D2}, {Rr}", f"v_fmac_f32_e32 v45, {D0}, {SC}", f"v_fmac_f32_e32 v68, {D1}, {SC}",
+                     f"v_fmac_f32_e32 v49, {D2}, {SC}"]
+        body += pre + rsq + nops(gap)
+        if rotate == "bpermute" and half == 0:
+            body += ["s_waitcnt lgkmcnt(0)"]
+        body += post
+    if rotate == "bpermute":
+        body += [f"ds_bpermute_b32 {r}, v59, {r}" for r in ("v45", "v68", "v49")]
+    return body
+
+
+class SymAlloc8(SymAlloc):
+    nreg = 112
+    R, U = 8, 1
+
+
+for nreg in (104, 112, 120):
+    for gap in (12, 24):
+        a8 = SymAlloc8(); a8.nreg = nreg
+        add(f"sym8_g{gap}_r{nreg}", f"pair-once, 8 rows per lane (2 sub-batches) + 3 ds_bpermute + 2 address ops, gap {gap}, {nreg} regs",
+            a8, sym_step8(gap), 1)
+a8 = SymAlloc8(); a8.nreg = 112
+add("sym8_arith", "pair-once, 8 rows per lane, arithmetic only, gap 24, 112 regs", a8, sym_step8(24, rotate=False, addr=False), 1)
+
+
 class SymAlloc2(SymAlloc):
     nreg = 112
     R, U = 4, 2
