@@ -12,11 +12,12 @@ update) over one synthetic Plummer-sphere state resident in HBM.  Rank 0 prints 
               both bodies (the reference's own VERSION 3 idea, kernel.cu:703-774, without atomics); one_sided:
               nbody::force_kernel_r4 evaluates every ordered interaction.  Both on 1..8 GPUs; at N = 1 the other mode
               is timed too and reported in "other_force_mode".
-* roofline  = the dominant force kernel against the fp32 vector peak: ALGORITHMIC flop = 20 per ordered interaction
-               x the interactions one launch accounts for / its HIP-event duration, measured in this
-              run on the stream the kernel runs on.  The pair-once kernel EXECUTES fewer (26 flop per unordered pair):
-              "frac_executed" says how busy the VALU really is.  "traffic" is the HBM bytes per launch from the
-              committed rocprofv3 PMC summary when one exists for this kernel and size, else null.
+* roofline  = the dominant force kernel against the fp32 vector peak: 20 flop x the pair evaluations one
+              launch EXECUTES / its HIP-event duration, measured in this run on the stream the kernel runs on.  For the
+              pair-once kernel that is half the ordered interactions it accounts for -- no 2x credit (SURVEY.md 8d);
+              the flop its instructions really perform (26 per unordered pair) and the credited reading are reported
+              under their own names.  "traffic" is the HBM bytes per launch from the committed rocprofv3 PMC summary
+              when one exists for this kernel and size, else null.
 * cpu_baseline = the CPU oracle's scalar all-pairs loop (a port; the reference has no CPU path), timed on this
               host's cores on a row slab of the same workload (N = 1 run only).
 Multi-GPU: total N is fixed, rows are sharded over the ranks => "scaling": "strong".
@@ -98,24 +99,31 @@ def executed_pairs(mode, n, split_len, rows_here):
 
 
 def roofline(mode, n, split_len, rows_here, steps, tm):
+    """the fraction is computed from EXECUTED pair evaluations x 20 flop, never from the 2x credit a
+    pair-once kernel could claim for the ordered interactions it accounts for.  Both other readings are reported beside
+    it under their own names."""
     force_s = max(tm["force_ms"] / 1e3, 1e-12)
     launches = max(tm["force_launches"], 1)
-    algorithmic = FLOP_PER_INTERACTION * rows_here * n * steps
     executed = executed_pairs(mode, n, split_len, rows_here) * steps
-    executed_flop = (FLOP_PER_INTERACTION if mode == "one_sided" else FLOP_PER_PAIR_ONCE) * executed
-    achieved = algorithmic / force_s / 1e12
+    achieved = FLOP_PER_INTERACTION * executed / force_s / 1e12
+    instr_flop = (FLOP_PER_INTERACTION if mode == "one_sided" else FLOP_PER_PAIR_ONCE) * executed / force_s / 1e12
+    credit = FLOP_PER_INTERACTION * rows_here * n * steps / force_s / 1e12
     traffic = committed_traffic(n, KERNEL_NAME[mode]) if rows_here == n else None
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
             "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
             "kernel": KERNEL_NAME[mode],
-            "algorithmic_flop_per_launch": algorithmic / launches,
+            "flop_per_launch": FLOP_PER_INTERACTION * executed / launches,
             "executed_pair_evaluations_per_s": executed / force_s,
-            "frac_executed": executed_flop / force_s / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+            "ordered_interactions_accounted_per_s": rows_here * n * steps / force_s,
+            "frac_instruction_flop": instr_flop / PEAK_FP32_VECTOR_TFLOPS,
+            "frac_if_credited_per_ordered_interaction": credit / PEAK_FP32_VECTOR_TFLOPS,
             "avg_launch_ms": tm["force_ms"] / launches, "launches": tm["force_launches"],
-            "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used; algorithmic = 20 flop "
-                    "per ordered interaction (SURVEY.md 8d); executed = 20 per ordered (one_sided) or 26 per unordered "
-                    "(pair_once) pair evaluation; rank 0's kernels"}
+            "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used.  achieved/frac: executed "
+                    "pair evaluations x 20 flop (SURVEY.md 8d).  frac_instruction_flop: the flop the kernel's instructions "
+                    "really perform (one_sided 20 per evaluation; pair_once 26: 3 sub, 9 fma, 4 mul, 1 rsq for TWO "
+                    "interactions).  frac_if_credited_per_ordered_interaction: 20 flop x the ordered interactions the "
+                    "launch accounts for -- NOT a utilisation figure for the pair-once kernel.  Rank 0's kernels."}
 
 
 def other_mode_leg(nb, mode, n, pos, vel, args):

@@ -63,6 +63,13 @@ def main(tag, rnd, n, kern="force_kernel", mode=""):
             inter = float(n) * float(n) / 64.0   # wave64 instructions' worth of ORDERED interactions
             out["valu_instructions_per_interaction"] = mean["SQ_INSTS_VALU"] / inter
             out["simd_cycles_per_interaction"] = cyc * 1024.0 / inter
+    if all(k in mean for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")) and durations:
+        # wave64 instructions x 64 lanes; an FMA is 2 flop, everything else 1 (v_sub_f32 is counted with the adds)
+        flop = 64.0 * (mean["SQ_INSTS_VALU_ADD_F32"] + mean["SQ_INSTS_VALU_MUL_F32"] + 2.0 * mean["SQ_INSTS_VALU_FMA_F32"] +
+                       mean["SQ_INSTS_VALU_TRANS_F32"])
+        out["rocprof_flop_per_launch"] = flop
+        out["rocprof_TFLOPs"] = flop / (out["avg_launch_ms_kernel_trace"] * 1e-3) / 1e12
+        out["rocprof_frac_of_fp32_peak_157.3"] = out["rocprof_TFLOPs"] / 157.3
     out["vgpr_count_reported"] = vgpr
     path = os.path.join(dst, f"{rnd}_pmc{'_' + mode if mode else ''}_n{n}.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
