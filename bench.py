@@ -36,7 +36,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_INTERACTION = 20.0        # SURVEY.md 8d (GPU Gems 3 ch.31 convention)
-FLOP_PER_PAIR_ONCE = 26.0          # executed by force_sym_kernel per unordered pair: 3 sub, 9 fma, 4 mul, 1 rsq
+# flop the instructions of one pair evaluation really perform (= what rocprofv3's SQ_INSTS_VALU_*_F32 counters add up to)
+FLOP_INSTRUCTIONS = {"one_sided": 19.0,   # 3 sub, 6 fma, 3 mul, 1 rsq
+                     "pair_once": 26.0}   # 3 sub, 9 fma, 4 mul, 1 rsq, for the two interactions of the pair
 KERNEL_NAME = {"one_sided": "nbody::force_kernel_r4", "pair_once": "nbody::force_sym_kernel"}
 PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md, chip-level parameters: 256 CU x 4 SIMD x 32 lanes x 2 x 2.4 GHz
 
@@ -106,7 +108,7 @@ def roofline(mode, n, split_len, rows_here, steps, tm):
     launches = max(tm["force_launches"], 1)
     executed = executed_pairs(mode, n, split_len, rows_here) * steps
     achieved = FLOP_PER_INTERACTION * executed / force_s / 1e12
-    instr_flop = (FLOP_PER_INTERACTION if mode == "one_sided" else FLOP_PER_PAIR_ONCE) * executed / force_s / 1e12
+    instr_flop = FLOP_INSTRUCTIONS[mode] * executed / force_s / 1e12
     credit = FLOP_PER_INTERACTION * rows_here * n * steps / force_s / 1e12
     traffic = committed_traffic(n, KERNEL_NAME[mode]) if rows_here == n else None
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
@@ -121,7 +123,7 @@ def roofline(mode, n, split_len, rows_here, steps, tm):
             "avg_launch_ms": tm["force_ms"] / launches, "launches": tm["force_launches"],
             "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used.  achieved/frac: executed "
                     "pair evaluations x 20 flop (SURVEY.md 8d).  frac_instruction_flop: the flop the kernel's instructions "
-                    "really perform (one_sided 20 per evaluation; pair_once 26: 3 sub, 9 fma, 4 mul, 1 rsq for TWO "
+                    "really perform (one_sided 19 per evaluation; pair_once 26: 3 sub, 9 fma, 4 mul, 1 rsq for TWO "
                     "interactions).  frac_if_credited_per_ordered_interaction: 20 flop x the ordered interactions the "
                     "launch accounts for -- NOT a utilisation figure for the pair-once kernel.  Rank 0's kernels."}
 
