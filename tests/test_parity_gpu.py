@@ -29,8 +29,11 @@ def nb():
     return nb
 
 
-def run_gpu(nb, pos, vel, dt, eps, nsteps, **kw):
+def run_gpu(nb, pos, vel, dt, eps, nsteps, mode="one_sided", **kw):
+    if mode == "pair_once":
+        kw.setdefault("split_len", 256 if pos.shape[0] < 8192 else nb.pair_once_split_len(pos.shape[0]))
     with nb.NBodySystem(pos.shape[0], **kw) as s:
+        s.set_force_mode(mode)
         s.setParticlesPosition(pos)
         s.setParticlesVelocity(vel)
         s.step_n(nsteps, dt, eps)
@@ -69,6 +72,9 @@ def test_coincident_bodies_and_zero_softening(nb):
 
 
 def test_empty_and_single_body(nb):
+    for mode in ("one_sided", "pair_once"):
+        p, v = run_gpu(nb, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), 1e-3, 1e-3, 2, mode)
+        assert p.shape == (0, 4) and v.shape == (0, 4)
     p, v = run_gpu(nb, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), 1e-3, 1e-3, 2)
     assert p.shape == (0, 4) and v.shape == (0, 4)
     pos = np.array([[1, 2, 3, 5]], dtype=np.float32)
@@ -79,13 +85,14 @@ def test_empty_and_single_body(nb):
 
 # ---- accelerations and steps against the oracle ------------------------------------------------------
 
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
 @pytest.mark.parametrize("n", [2, 63, 255, 256, 257, 1000, 4097, 20000])
-def test_one_step_matches_oracle_ragged_sizes(nb, oracle_mod, n):
+def test_one_step_matches_oracle_ragged_sizes(nb, oracle_mod, n, mode):
     pos, vel = nb.uniform_cube(n, seed=100 + n, random_masses=True, speed=0.2)
-    a = gpu_accel(nb, pos, 1e-3)
+    a = run_gpu(nb, pos, np.zeros_like(vel), 1.0, 1e-3, 1, mode)[1][:, :3]   # dt = 1, v0 = 0: v = a
     a64 = oracle_mod.accel_f64(pos, eps=1e-3)
     assert np.linalg.norm(a - a64) / np.linalg.norm(a64) < TOL
-    p, v = run_gpu(nb, pos, vel, 1e-3, 1e-3, 3)
+    p, v = run_gpu(nb, pos, vel, 1e-3, 1e-3, 3, mode)
     pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=3)
     assert rel_state_error(p, pr) < TOL and rel_state_error(v, vr) < TOL
     assert np.array_equal(p[:, 3], pos[:, 3]) and np.array_equal(v[:, 3], vel[:, 3])  # mass / vel.w untouched
@@ -99,32 +106,35 @@ def test_gpu_is_no_worse_than_reference_order_fp32(nb, oracle_mod):
     assert e_gpu < TOL and e_gpu < 4 * e_ref + 1e-7
 
 
-def test_config2_n65536_ten_steps(nb, oracle_mod):
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
+def test_config2_n65536_ten_steps(nb, oracle_mod, mode):
     """BASELINE.json configs[1]: N = 65 536 fp32, LDS tile 256, final state vs CPU within 1e-5 rel."""
     pos, vel = nb.plummer(65536, seed=nb.CONFIG_SEED[2])
-    p, v = run_gpu(nb, pos, vel, 1e-3, 1e-3, 10)
+    p, v = run_gpu(nb, pos, vel, 1e-3, 1e-3, 10, mode)
     pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=10)
     assert rel_state_error(p, pr) < TOL and rel_state_error(v, vr) < TOL
 
 
-def test_golden_fixtures(nb, golden_dir):
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
+def test_golden_fixtures(nb, golden_dir, mode):
     files = sorted(glob.glob(os.path.join(golden_dir, "f1_*.npz")))
     assert len(files) >= 4
     for f in files:
         g = np.load(f)
         for k in g["steps"]:
-            p, v = run_gpu(nb, g["pos0"], g["vel0"], float(g["dt"]), float(g["softening"]), int(k))
+            p, v = run_gpu(nb, g["pos0"], g["vel0"], float(g["dt"]), float(g["softening"]), int(k), mode)
             tol = TOL if k <= 10 else 5e-5  # 100 steps of a chaotic system: rounding differences grow
             assert rel_state_error(p, g[f"p64_{k}"]) < tol and rel_state_error(v, g[f"v64_{k}"]) < tol, (f, k)
             assert rel_state_error(p, g[f"p32_{k}"]) < tol, (f, k)
 
 
-def test_reference_constants_and_padding(nb, oracle_mod):
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
+def test_reference_constants_and_padding(nb, oracle_mod, mode):
     """The reference's own configuration: dt = 0.008, VERSION 3 softening, roundup(n,256)+1 zero-mass padding."""
     pos, vel = nb.plummer(3000, seed=5)
     ppos, pvel = nb.pad_reference_style(pos, vel)
-    p, v = run_gpu(nb, pos, vel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 5)
-    pp, vp = run_gpu(nb, ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 5)
+    p, v = run_gpu(nb, pos, vel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 5, mode)
+    pp, vp = run_gpu(nb, ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 5, mode)
     n = pos.shape[0]
     # padding bodies sit at the origin with zero mass: real bodies' results are unchanged to rounding
     # (not bit-exact: the split boundaries depend on n_total)
