@@ -71,6 +71,19 @@ def test_coincident_bodies_and_zero_softening(nb):
         assert np.array_equal(a[0], a[1])
 
 
+def test_initialize_picks_the_force_mode_by_size(nb, oracle_mod):
+    for n, want_len in ((5000, nb.default_split_len(5000)), (65536, nb.pair_once_split_len(65536))):
+        pos, vel = nb.plummer(n, seed=3)
+        with nb.initialize(n, force_mode="auto") as s:
+            assert s.split_len == want_len
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            s.step(1e-3, 1e-3)
+            p, v = s.download()
+        pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-3, nsteps=1)
+        assert rel_state_error(p, pr) < TOL and rel_state_error(v, vr) < TOL
+
+
 def test_empty_and_single_body(nb):
     for mode in ("one_sided", "pair_once"):
         p, v = run_gpu(nb, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), 1e-3, 1e-3, 2, mode)
