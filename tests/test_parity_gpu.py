@@ -464,6 +464,20 @@ def test_symmetric_mode_row_shards_with_a_manual_exchange(nb):
             s.set_force_mode("symmetric")
 
 
+def test_force_mode_can_be_switched_on_a_live_context(nb):
+    n, L = 8192, 1024
+    pos, vel = nb.plummer(n, seed=12)
+    want = {m: sym_run(nb, pos, vel, 1e-3, 1e-3, 1, m, L) for m in ("one_sided", "symmetric")}
+    with nb.NBodySystem(n, split_len=L) as s:
+        for m in ("symmetric", "one_sided", "symmetric", "one_sided"):   # the partial-sum array grows on the way back
+            s.set_force_mode(m)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            s.step(1e-3, 1e-3)
+            p, v = s.download()
+            assert np.array_equal(p, want[m][0]) and np.array_equal(v, want[m][1]), m
+
+
 def test_symmetric_mode_zero_softening_and_limits(nb):
     pos, vel = nb.uniform_cube(16384, seed=9, random_masses=True)
     pos[5] = pos[6]                                   # two coincident bodies
