@@ -47,6 +47,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def cpu_quota_cores():
+    """CPU time this process may use per second of wall time (cgroup v2 cpu.max / v1 cfs quota), in cores; None = no limit."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except Exception:
+        return None
+
+
 def cpu_baseline(pos, softening, target_seconds):
     """Scalar all-pairs rows of the oracle on all host cores, on a row slab sized to ~target_seconds."""
     import oracle
@@ -63,7 +78,12 @@ def cpu_baseline(pos, softening, target_seconds):
     t = time.perf_counter()
     oracle.accel_f32(pos, 0, rows, 0, n, softening, threads=cores)
     dt = time.perf_counter() - t
+    rows1 = max(1, int(rows / cores / 8))        # about an eighth of the all-core time, on one core
+    t = time.perf_counter()
+    oracle.accel_f32(pos, 0, rows1, 0, n, softening, threads=1)
+    dt1 = time.perf_counter() - t
     return {"value": rows * n / dt, "unit": "interactions/s", "cores": cores, "kind": "port",
+            "value_one_core": rows1 * n / dt1, "cpu_quota_cores": cpu_quota_cores(),
             "sample": f"rows [0,{rows}) x all {n} columns of the same state, {dt:.1f} s, "
                       f"oracle/nbody_oracle.c reference-order fp32 (extrapolates linearly in rows)"}
 
