@@ -66,7 +66,9 @@ def cpu_baseline(pos, softening, target_seconds):
     """Scalar all-pairs rows of the oracle on all host cores, on a row slab sized to ~target_seconds."""
     import oracle
     oracle.build()
-    cores = oracle.host_threads()
+    visible = oracle.host_threads()
+    quota = cpu_quota_cores()                     # the GPU box shows 256 CPUs and grants 16 cores' worth of time
+    cores = max(1, min(visible, int(round(quota)))) if quota else visible
     n = pos.shape[0]
     rows = min(n, 8 * cores)
     t = time.perf_counter()
@@ -83,7 +85,7 @@ def cpu_baseline(pos, softening, target_seconds):
     oracle.accel_f32(pos, 0, rows1, 0, n, softening, threads=1)
     dt1 = time.perf_counter() - t
     return {"value": rows * n / dt, "unit": "interactions/s", "cores": cores, "kind": "port",
-            "value_one_core": rows1 * n / dt1, "cpu_quota_cores": cpu_quota_cores(),
+            "value_one_core": rows1 * n / dt1, "cpus_visible": visible, "cpu_quota_cores": quota,
             "sample": f"rows [0,{rows}) x all {n} columns of the same state, {dt:.1f} s, "
                       f"oracle/nbody_oracle.c reference-order fp32 (extrapolates linearly in rows)"}
 
