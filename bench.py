@@ -47,28 +47,12 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_quota_cores():
-    """CPU time this process may use per second of wall time (cgroup v2 cpu.max / v1 cfs quota), in cores; None = no limit."""
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if quota == "max" else float(quota) / float(period)
-    except Exception:
-        pass
-    try:
-        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        return None if quota <= 0 else quota / period
-    except Exception:
-        return None
-
-
 def cpu_baseline(pos, softening, target_seconds):
     """Scalar all-pairs rows of the oracle on all host cores, on a row slab sized to ~target_seconds."""
     import oracle
     oracle.build()
-    visible = oracle.host_threads()
-    quota = cpu_quota_cores()                     # the GPU box shows 256 CPUs and grants 16 cores' worth of time
-    cores = max(1, min(visible, int(round(quota)))) if quota else visible
+    visible, quota = oracle.cpus_visible(), oracle.cpu_quota_cores()
+    cores = oracle.host_threads()                 # the GPU box shows 256 CPUs and grants 16 cores' worth of time
     n = pos.shape[0]
     rows = min(n, 8 * cores)
     t = time.perf_counter()

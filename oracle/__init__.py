@@ -73,12 +73,35 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
-def host_threads() -> int:
-    """Cores this process may run on (``sched_getaffinity``), as BASELINE.md section 3 asks."""
+def cpus_visible() -> int:
+    """CPUs this process may be scheduled on (``sched_getaffinity``)."""
     try:
         return len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
         return os.cpu_count() or 1
+
+
+def cpu_quota_cores():
+    """CPU time per second of wall time the cgroup grants (v2 ``cpu.max`` / v1 cfs quota), in cores; None = unlimited."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except Exception:
+        return None
+
+
+def host_threads() -> int:
+    """Worker threads worth starting: the visible CPUs, capped by the cgroup's CPU quota (a GPU box shows 256 CPUs and
+    grants 16 cores' worth of time; 256 threads on it run slower than 16)."""
+    quota = cpu_quota_cores()
+    visible = cpus_visible()
+    return max(1, min(visible, int(round(quota)))) if quota else visible
 
 
 def _f32(a) -> np.ndarray:
