@@ -522,17 +522,21 @@ int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
     return NBODY_OK;
 }
 
-// Largest register blocking that still leaves every CU several workgroups; 4 rows per lane (4 v_rsq_f32 per
-// batch, 8 waves per SIMD) measured fastest.  Speed only: each row's sum is the same FMA chain whatever the
-// blocking.
+// Largest register blocking that still fills the chip evenly; 4 rows per lane (the hand-allocated kernel) is fastest
+// once there are enough workgroups.  With short splits (<= 512 columns: one or two LDS tiles per workgroup) a
+// workgroup is over quickly and what counts is how evenly the last ones spread: measured at the reference's N = 20 225
+// (split 256) 1 row per lane 0.145 ms, 2: 0.152, 4: 0.156; from N = 32 768 on 4 wins (tools/small_n.py).  Speed only:
+// each row's sum is the same FMA chain whatever the blocking.
 static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
 {
     if (c->rows_per_lane)
         return c->rows_per_lane;
-    const int64_t want = 4LL * c->cu_count;
+    const bool short_splits = c->split_len <= 512;
+    const int64_t want[2] = {(short_splits ? 10LL : 4LL) * c->cu_count, (short_splits ? 20LL : 4LL) * c->cu_count};
+    int i = 0;
     for (int rpl : {4, 2}) {
         int64_t blocks = (c->row_count + (int64_t)kTile * rpl - 1) / ((int64_t)kTile * rpl) * split_count;
-        if (blocks >= want)
+        if (blocks >= want[i++])
             return rpl;
     }
     return 1;
