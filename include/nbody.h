@@ -163,8 +163,9 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
  * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
 /* The split length to create a pair-once context with.  A function of n_total ONLY (split boundaries define the
- * summation order, so they must not depend on the sharding): 1024 up to 2^21 bodies -- the kernel's rows per pass, the
- * finest grid that keeps every wave busy -- then 2048 (N = 2^22) and 4096, so that the partial sums
+ * summation order, so they must not depend on the sharding): 1024 from 204 800 to 2^21 bodies -- the kernel's rows per
+ * pass, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles below that (small systems
+ * need more, smaller tiles to fill the chip), then 2048 (N = 2^22) and 4096, so that the partial sums
  * (n_total^2 / split_len x 16 B over all contexts) would still fit one GPU. */
 int64_t nbody_pair_once_split_len(int64_t n_total);
 #define NBODY_SYM_GROUPS 8

@@ -114,8 +114,13 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
     // N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms; 4096 leaves 3 workgroups per CU: 441 against 392 ms for one of 8 ranks
     // at N = 2^22).  The two partial-sum arrays together hold n_total^2 / split_len x 16 B: 17 GB at N = 2^20, and the
     // length doubles where that would pass 150 GB (137 GB at N = 2^22 with 2048: one GPU can still hold it).
+    // Below ~200 000 bodies 1024-body tiles are too few to fill 256 CUs x 5 workgroups evenly (N = 131072: 2016 tiles):
+    // the splits shrink to n_total / 200, in whole 256-body tiles, and the tile kernel runs with 2 or 1 wave per workgroup.
     const double pairs16 = 16.0 * (double)n_total * (double)n_total;
-    int64_t len = 1024;
+    int64_t len = n_total / 200 / kTile * kTile;
+    if (len < 1024)
+        return len < kTile ? kTile : len;
+    len = 1024;
     while (len < 4096 && pairs16 / (double)len > 150e9)
         len *= 2;
     return len;

@@ -5,7 +5,7 @@
 // shared-memory and global float atomics -- which its author names as the bottleneck (kernel.cu:757) and which
 // make the result order-dependent.  This kernel keeps the idea and drops the atomics:
 //
-//   * tiles are pairs of splits (R, C), split_len bodies each; ONE 256-thread workgroup (4 wave64) per tile, so every
+//   * tiles are pairs of splits (R, C), split_len bodies each; ONE workgroup (4 wave64; 2 or 1 for short splits) per tile, so every
 //     partial sum is produced by exactly one workgroup (d = (C - R) mod n_splits, the tile's ring distance):
 //        rows b in R, columns c in C:  P_row[d][b]    = sum_c m_c f(b,c)   (row side, registers)
 //                                      P_col[R][d][c] = -sum_b m_b f(b,c)  (column side, LDS)
@@ -31,11 +31,10 @@
 
 namespace nbody {
 
-constexpr int kSymThreads = 256;
-constexpr int kSymWaves = kSymThreads / 64;
+// A tile's workgroup has W wave64 (W x 256 rows per pass): 4 for splits of 1024 bodies or more, fewer for the shorter
+// splits of small systems, so that no wave is left without rows (sym_waves()).
 constexpr int kSymRows = 4;  // rows per lane
-constexpr int kSymRowsPerPass = kSymWaves * 64 * kSymRows;
-constexpr int kSymStageFloats = kSymWaves * 64 * 4;  // one 64-body group (1 KiB, 1 KiB-aligned) per wave
+constexpr int kSymStageFloatsPerWave = 64 * 4;  // one 64-body group (1 KiB, 1 KiB-aligned) per wave
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v)
@@ -129,11 +128,12 @@ struct SymLds {
     float *sx, *sy, *sz;
 };
 
+template <int W>
 __device__ __forceinline__ SymLds sym_lds(float *smem, int L)
 {
     SymLds s;
     s.stage = reinterpret_cast<float4 *>(smem) + (threadIdx.x >> 6) * 64;
-    s.sx = smem + kSymStageFloats;
+    s.sx = smem + W * kSymStageFloatsPerWave;
     s.sy = s.sx + L;
     s.sz = s.sy + L;
     return s;
@@ -151,12 +151,13 @@ __device__ __forceinline__ int sym_group(int g, int wave, int spacing, int G)
 }
 
 // ---- off-diagonal tiles (I < J) ------------------------------------------------------------------------------
-template <bool GUARD>
-__global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
+template <int W, bool GUARD>
+__global__ __launch_bounds__(64 * W) void force_sym_kernel(SymArgs a)
 {
+    constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int L = a.split_len, G = L / 64;
-    const SymLds lds = sym_lds(smem, L);
+    const SymLds lds = sym_lds<W>(smem, L);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int2 t = a.tiles[blockIdx.x];
     const int rowbase = t.x * L, colbase = t.y * L;
@@ -247,12 +248,13 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_kernel(SymArgs a)
 // < column index are kept (drops the self pair too); both sides end in P_row[B].  PPS: eps_ij^2 = eps^2 + eps_i^2 +
 // eps_j^2 (symmetric in the pair, so it fits the pair-once scheme): one extra add per pair and a 64-float LDS stage
 // of the group's eps_j^2 per wave.  Same data flow and summation order as the hand-scheduled kernel above.
-template <bool DIAG, bool GUARD, bool PPS>
-__global__ __launch_bounds__(kSymThreads) void force_sym_general_kernel(SymArgs a)
+template <int W, bool DIAG, bool GUARD, bool PPS>
+__global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
 {
+    constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int L = a.split_len, G = L / 64;
-    const SymLds lds = sym_lds(smem, L);
+    const SymLds lds = sym_lds<W>(smem, L);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *estage = lds.sz + L + wave * 64;
     const int2 t = DIAG ? a.diag_tiles[blockIdx.x] : a.tiles[blockIdx.x];
@@ -366,14 +368,18 @@ __global__ __launch_bounds__(kSymThreads) void force_sym_general_kernel(SymArgs 
             out[c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
+// waves per tile workgroup: W x 256 rows per pass must not exceed the split
+static int sym_waves(int split_len) { return split_len >= 1024 ? 4 : split_len >= 512 ? 2 : 1; }
+
 // the column-group stage, three column-sum arrays, and the per-wave eps_j^2 stage of the per-particle-softening variant
 size_t symmetric_lds_bytes(int split_len)
 {
-    return (size_t)kSymStageFloats * sizeof(float) + (size_t)split_len * 12 + (size_t)kSymWaves * 64 * sizeof(float);
+    const size_t w = (size_t)sym_waves(split_len);
+    return w * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + w * 64 * sizeof(float);
 }
 
 template <typename K>
-static hipError_t sym_launch(K kernel, int blocks, size_t lds, const SymArgs &a, hipStream_t stream)
+static hipError_t sym_launch(K kernel, int blocks, int waves, size_t lds, const SymArgs &a, hipStream_t stream)
 {
     if (blocks <= 0)
         return hipSuccess;
@@ -381,28 +387,48 @@ static hipError_t sym_launch(K kernel, int blocks, size_t lds, const SymArgs &a,
                                        (int)lds);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kSymThreads), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
+}
+
+template <int W>
+static hipError_t sym_launch_tiles(const SymArgs &a, size_t lds, hipStream_t stream)
+{
+    if (a.eps_pp)  // per-particle softening: the compiler-scheduled kernel (a particle may have eps = 0: keep the guard at eps = 0)
+        return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<W, false, false, true>, a.n_tiles, W, lds, a, stream)
+                            : sym_launch(&force_sym_general_kernel<W, false, true, true>, a.n_tiles, W, lds, a, stream);
+    return a.eps2 > 0.f ? sym_launch(&force_sym_kernel<W, false>, a.n_tiles, W, lds, a, stream)
+                        : sym_launch(&force_sym_kernel<W, true>, a.n_tiles, W, lds, a, stream);
+}
+
+template <int W>
+static hipError_t sym_launch_diag(const SymArgs &a, size_t lds, hipStream_t stream)
+{
+    if (a.eps_pp)
+        return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<W, true, false, true>, a.n_diag, W, lds, a, stream)
+                            : sym_launch(&force_sym_general_kernel<W, true, true, true>, a.n_diag, W, lds, a, stream);
+    return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<W, true, false, false>, a.n_diag, W, lds, a, stream)
+                        : sym_launch(&force_sym_general_kernel<W, true, true, false>, a.n_diag, W, lds, a, stream);
 }
 
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
 {
     const size_t lds = symmetric_lds_bytes(a.split_len);
-    if (a.eps_pp)  // per-particle softening: the compiler-scheduled kernel (a particle may have eps = 0: keep the guard at eps = 0)
-        return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<false, false, true>, a.n_tiles, lds, a, stream)
-                            : sym_launch(&force_sym_general_kernel<false, true, true>, a.n_tiles, lds, a, stream);
-    return a.eps2 > 0.f ? sym_launch(&force_sym_kernel<false>, a.n_tiles, lds, a, stream)
-                        : sym_launch(&force_sym_kernel<true>, a.n_tiles, lds, a, stream);
+    switch (sym_waves(a.split_len)) {
+    case 4: return sym_launch_tiles<4>(a, lds, stream);
+    case 2: return sym_launch_tiles<2>(a, lds, stream);
+    default: return sym_launch_tiles<1>(a, lds, stream);
+    }
 }
 
 hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream)
 {
     const size_t lds = symmetric_lds_bytes(a.split_len);
-    if (a.eps_pp)
-        return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<true, false, true>, a.n_diag, lds, a, stream)
-                            : sym_launch(&force_sym_general_kernel<true, true, true>, a.n_diag, lds, a, stream);
-    return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<true, false, false>, a.n_diag, lds, a, stream)
-                        : sym_launch(&force_sym_general_kernel<true, true, false>, a.n_diag, lds, a, stream);
+    switch (sym_waves(a.split_len)) {
+    case 4: return sym_launch_diag<4>(a, lds, stream);
+    case 2: return sym_launch_diag<2>(a, lds, stream);
+    default: return sym_launch_diag<1>(a, lds, stream);
+    }
 }
 
 // ---- the canonical summation of the pair-once partial sums (HBM-bound, O(N n_splits)) ------------------------------
