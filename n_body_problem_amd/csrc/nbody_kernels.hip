@@ -170,6 +170,17 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t"
 // one column: wait for its LDS read, phase 1 for the four rows, the four rsq, issue the NEXT read, idle 24 wait
 // states (20-28 measured equally good on the kernel, 12 and 32 about 2 % worse), phase 4
+// Wave priority (measured after the gap was tuned): priority 2 for the PRE + v_rsq_f32 phases, 0 for the POST phase --
+// the SIMD then issues a waiting wave's rsq batch before another wave's POST stretch, which does by arbitration what the
+// idle gap does by waiting: 256.2-257.1 ms per N = 2^20 pass against 260.7 ms, and the gap length stops mattering
+// (0 / 6 / 24 wait states: 256.2 / 256.8 / 257.1 ms).
+#ifndef NB_R4_GAP
+#define NB_R4_GAP "s_nop 5\n\t"
+#endif
+#ifndef NB_R4_PRIO_POST
+#define NB_R4_PRIO_POST "s_setprio 0\n\t"
+#define NB_R4_PRIO_PRE "s_setprio 2\n\t"
+#endif
 #define NB_COLUMN(PX, PY, PZ, PM, NEXT, GRD)                                                                     \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
     NB_PRE(PX, PY, PZ, "v9", "v10", "v11", "v36", "v37", "v38", "v39", GRD)                                      \
@@ -177,12 +188,14 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     NB_PRE(PX, PY, PZ, "v17", "v18", "v19", "v44", "v45", "v46", "v47", GRD)                                     \
     NB_PRE(PX, PY, PZ, "v21", "v22", "v23", "v48", "v49", "v50", "v51", GRD)                                     \
     "v_rsq_f32_e32 v36, v36\n\tv_rsq_f32_e32 v40, v40\n\tv_rsq_f32_e32 v44, v44\n\tv_rsq_f32_e32 v48, v48\n\t"       \
-    NEXT "s_nop 15\n\ts_nop 7\n\t"                                                                               \
+    NEXT NB_R4_GAP NB_R4_PRIO_POST                                                                               \
     NB_POST(PM, "v12", "v25", "v26", "v36", "v37", "v38", "v39", "v33")                                          \
     NB_POST(PM, "v16", "v27", "v28", "v40", "v41", "v42", "v43", "v34")                                          \
     NB_POST(PM, "v20", "v29", "v30", "v44", "v45", "v46", "v47", "v33")                                          \
-    NB_POST(PM, "v24", "v31", "v32", "v48", "v49", "v50", "v51", "v34")
+    NB_POST(PM, "v24", "v31", "v32", "v48", "v49", "v50", "v51", "v34")                                          \
+    NB_R4_PRIO_PRE
 #define NB_TILE_LOOP(GRD)                                                                                        \
+    NB_R4_PRIO_PRE                                                                                               \
     "ds_read_b128 v[0:3], v52\n\t"                                                                               \
     "s_mov_b32 %[cnt], 64\n"                                                                                     \
     "1:\n\t"                                                                                                     \
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
 template <bool GUARD>

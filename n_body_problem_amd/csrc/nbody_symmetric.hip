@@ -70,8 +70,17 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     "v_mul_f32_e32 " SC ", " M ", " T "\n\tv_mul_f32_e32 " R ", " PM ", " T "\n\t"                                    \
     "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t" \
     "v_fmac_f32_e32 v45, " D0 ", " SC "\n\tv_fmac_f32_e32 v68, " D1 ", " SC "\n\tv_fmac_f32_e32 v49, " D2 ", " SC "\n\t"
+// Wave priority: a wave runs its PRE + v_rsq_f32 phases at priority 2 and drops to 0 for the POST phase, so the SIMD
+// issues a waiting wave's rsq batch before another wave's long POST stretch and the wave then sits out its slow window
+//  while the others issue -- measured 1.7-2.3 % faster than equal priorities, and with it the
+// explicit idle gap hardly matters any more (0 / 6 / 12 / 20 / 28 wait states: 194.0 / 193.7 / 194.3 / 194.5 / 195.1 ms
+// against 198.3 ms without priorities, same box).
+#ifndef NB_SYM_PRIO_POST
+#define NB_SYM_PRIO_POST "s_setprio 0\n\t"
+#define NB_SYM_PRIO_PRE "s_setprio 2\n\t"
+#endif
 #ifndef NB_SYM_GAP
-#define NB_SYM_GAP "s_nop 11\n\t"
+#define NB_SYM_GAP "s_nop 5\n\t"
 #endif
 // The column sums move one lane per step through the LDS crossbar (ds_bpermute_b32, v59 = 4 * ((lane + 1) mod 64)):
 // three v_mov_b32_dpp wave_rol:1 measured 38 VALU cycles a step (tools/gen_sched2.py), the permutes 6.  LDS operations
@@ -92,16 +101,19 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     NEXT                                                                                                         \
     NB_SYM_GAP                                                                                                   \
     "s_waitcnt lgkmcnt(1)\n\t"                                                                                   \
+    NB_SYM_PRIO_POST                                                                                             \
     SY_POST(PM, "v15", "v53", "v54", "v52", "v28", "v29", "v30", "v31", "v44", "v46", "v47")                     \
     SY_POST(PM, "v19", "v57", "v58", "v56", "v32", "v33", "v34", "v35", "v48", "v50", "v51")                     \
     SY_POST(PM, "v23", "v61", "v62", "v60", "v36", "v37", "v38", "v39", "v44", "v46", "v47")                     \
     SY_POST(PM, "v27", "v65", "v66", "v64", "v40", "v41", "v42", "v43", "v48", "v50", "v51")                     \
+    NB_SYM_PRIO_PRE                                                                                              \
     SY_ROTATE
 #define SY_GROUP_LOOP(GRD)                                                                                       \
     "s_waitcnt lgkmcnt(0)\n\t" /* nothing of the compiler's may be counted by the waits below */                 \
     "v_and_or_b32 v0, v1, v55, v10\n\t"                                                                          \
     "ds_read_b128 v[2:5], v0\n\t"                                                                                \
     SY_ROTATE /* of zeros: primes the in-order LDS queue so that every step sees the same pattern */             \
+    NB_SYM_PRIO_PRE                                                                                              \
     "s_mov_b32 %[cnt], 32\n"                                                                                     \
     "1:\n\t"                                                                                                     \
     SY_STEP("v2", "v3", "v4", "v5", "ds_read_b128 v[6:9], v0\n\t", GRD)                                          \
@@ -109,6 +121,7 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
 // ring distance of the tile (R, C): its slot in the partial-sum arrays
