@@ -126,7 +126,7 @@ class SymAlloc:
     R, U = 4, 1
 
 
-def sym_step(gap, rotate=True, addr=True, post_order="row", halves=False):
+def sym_step(gap, rotate=True, addr=True, post_order="row", halves=False, prio=None):
     """rotate: True/"wave_rol" = 3 x v_mov_b32_dpp wave_rol:1; "row_ror" = 3 x v_mov_b32_dpp row_ror:1 (cost probe);
     "bpermute" = 3 x ds_bpermute_b32 through the LDS crossbar, waited for just before the POST phase."""
     px, py, pz, pm = "v2", "v3", "v4", "v5"
@@ -157,6 +157,8 @@ def sym_step(gap, rotate=True, addr=True, post_order="row", halves=False):
         body += nops(gap)
         if rotate == "bpermute":
             body += ["s_waitcnt lgkmcnt(0)"]
+        if prio:
+            body += [f"s_setprio {prio[1]}"]
         if post_order == "row":
             for k in grp:
                 body += post[k]
@@ -164,6 +166,8 @@ def sym_step(gap, rotate=True, addr=True, post_order="row", halves=False):
             for i in range(10):
                 for k in grp:
                     body.append(post[k][i])
+    if prio:
+        body += [f"s_setprio {prio[0]}"]
     if rotate == "bpermute":
         body += [f"ds_bpermute_b32 {r}, v59, {r}" for r in ("v45", "v68", "v49")]
     elif rotate:
@@ -271,6 +275,15 @@ add("sym_bperm_full24", "pair-once step + 3 ds_bpermute_b32 + 2 address ops, gap
 al80 = SymAlloc(); al80.nreg = 80
 add("sym_bperm_full_r80", "pair-once step + 3 ds_bpermute_b32 + 2 address ops, gap 12, 80 regs", al80, sym_step(12, rotate="bpermute"), 2)
 add("sym_full_r80", "pair-once step + 3 DPP wave_rol + 2 address ops, gap 12, 80 regs", al80, sym_step(12), 2)
+for nreg_p in (80, 96):
+    alp = SymAlloc(); alp.nreg = nreg_p
+    for gap_p in (0, 6, 12):
+        add(f"sym_prio20_g{gap_p}_r{nreg_p}", f"pair-once full step, s_setprio 2 (PRE,rsq) / 0 (POST), gap {gap_p}, {nreg_p} regs", alp,
+            sym_step(gap_p, rotate="bpermute", prio=(2, 0)), 2)
+    add(f"sym_prio02_r{nreg_p}", f"pair-once full step, s_setprio 0 (PRE,rsq) / 2 (POST), gap 12, {nreg_p} regs", alp,
+        sym_step(12, rotate="bpermute", prio=(0, 2)), 2)
+    add(f"sym_arith_prio_r{nreg_p}", f"pair-once arithmetic only, s_setprio 2/0, gap 0, {nreg_p} regs", alp,
+        sym_step(0, rotate=False, addr=False, prio=(2, 0)), 2)
 add("sym_stage", "pair-once step, POST stage by stage, gap 12, 5 waves", al, sym_step(12, rotate=False, addr=False, post_order="stage"), 2)
 add("sym_halves", "pair-once step, two 2-row half batches, gap 12 each, 5 waves", al, sym_step(12, rotate=False, addr=False, halves=True), 2)
 add("sym_halves0", "pair-once step, two 2-row half batches, no gap, 5 waves", al, sym_step(0, rotate=False, addr=False, halves=True), 2)
