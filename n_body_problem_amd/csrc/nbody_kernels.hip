@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
             const float4 pn = cur[(jj + 1) & (kTile - 1)];  // the next column's LDS read travels during the gap
             __builtin_amdgcn_sched_barrier(0);
             idle_gap<RPL>();  // phase 3: sit out the slow window
+            __builtin_amdgcn_s_setprio(0);  // phases 1-2 run at priority 2, phase 4 at 0 (see NB_R4_PRIO_* below)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {  // phase 4: m_j / (r^2+eps^2)^(3/2) and the accumulation
@@ -130,8 +131,11 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
                 az[k] = __builtin_fmaf(dz[k], s, az[k]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_sched_barrier(0);
             pj = pn;
         }
+        __builtin_amdgcn_s_setprio(0);
 
         if (t + 1 < ntiles) {
             tile[(t + 1) & 1][tid] = stage;
