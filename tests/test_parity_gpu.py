@@ -71,6 +71,24 @@ def test_coincident_bodies_and_zero_softening(nb):
         assert np.array_equal(a[0], a[1])
 
 
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
+def test_linearity_in_mass_and_translation(nb, mode):
+    """Size-independent properties: accelerations are linear in the masses (a power-of-two factor: bit for bit, since it
+    only shifts exponents), and a rigid translation changes them by rounding only."""
+    n = 30000
+    pos, _ = nb.plummer(n, seed=21)
+    zero = np.zeros_like(pos)
+    a1 = run_gpu(nb, pos, zero, 1.0, 1e-2, 1, mode)[1][:, :3]
+    heavy = pos.copy()
+    heavy[:, 3] *= 4.0
+    a4 = run_gpu(nb, heavy, zero, 1.0, 1e-2, 1, mode)[1][:, :3]
+    assert np.array_equal(a4, 4.0 * a1)
+    moved = pos.copy()
+    moved[:, :3] += np.array([0.25, -0.5, 0.125], np.float32)      # exactly representable shifts of O(1) coordinates
+    am = run_gpu(nb, moved, zero, 1.0, 1e-2, 1, mode)[1][:, :3]
+    assert np.linalg.norm(am - a1) / np.linalg.norm(a1) < 1e-5
+
+
 def test_initialize_picks_the_force_mode_by_size(nb, oracle_mod):
     for n, want_len in ((5000, nb.default_split_len(5000)), (65536, nb.pair_once_split_len(65536))):
         pos, vel = nb.plummer(n, seed=3)
