@@ -187,6 +187,7 @@ def main():
                     help="pair_once (= symmetric): each unordered pair once; one_sided: every ordered interaction")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sanity", action="store_true", help="skip the energy / replica checks around the timed region")
     ap.add_argument("--no-extra-legs", "--no-pair-once", dest="no_extra_legs", action="store_true",
                     help="skip the extra legs (the other force mode, the reference's N = 20000)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -238,6 +239,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # outside the timed region: the energy before and after, and a check that every rank ends with the same positions
+    e_before = None if args.no_sanity else system.energy(args.softening)
     kernels.timing(True)
     for _ in range(args.warmup):
         system.step(args.dt, args.softening, sync=False)
@@ -256,6 +259,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = kernels.read_timing()
+    kernels.timing(False)
+    sanity = None
+    if not args.no_sanity:
+        e_after = system.energy(args.softening)
+        digest = system.positions.view(torch.int32).to(torch.int64).sum().reshape(1)
+        lo, hi = digest.clone(), digest.clone()
+        if world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        sanity = {"energy_before": float(e_before[2]), "energy_after": float(e_after[2]),
+                  "dE_over_E0": float((e_after[2] - e_before[2]) / abs(e_before[2])),
+                  "steps_between": args.warmup + args.steps,
+                  "position_replicas_identical_on_all_ranks": bool(int(lo.item()) == int(hi.item()))}
 
     out = None
     if rank == 0:
@@ -286,6 +302,7 @@ def main():
             "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
             "update_ms_per_step": tm["update_ms"] / args.steps,
             "device": info,
+            "sanity": sanity,
         }
         if world == 1 and not args.no_extra_legs:
             out["other_force_mode"] = other_mode_leg(nb, "one_sided" if mode == "pair_once" else "pair_once", n, pos, vel, args)

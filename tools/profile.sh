@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="$REPO/bench.py --no-cpu-baseline --no-extra-legs $*"
+BENCH="$REPO/bench.py --no-cpu-baseline --no-extra-legs --no-sanity $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $BENCH --steps 3 --warmup 1 > "$OUT/trace.log" 2>&1 || echo "trace failed"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python3 $BENCH --steps 2 --warmup 0 > "$OUT/pmc_$C.log" 2>&1 || echo "pmc $C failed"
