@@ -292,6 +292,7 @@ add("sym_halves0", "pair-once step, two 2-row half batches, no gap, 5 waves", al
 TEMPLATE = r'''// GENERATED by tools/gen_sched2.py -- do not edit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 %(kernels)s
 template <typename Kern>
@@ -301,8 +302,11 @@ static void run(const char *name, Kern kern, int cus, double units_per_body, int
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0);
     if (occ > 8) occ = 8;
     const int blocks = cus * occ, nw = blocks * 4;
+    // UBENCH_TICKS (100 MHz real-time ticks per measurement, default 30000 = 0.3 ms): long runs (3000000 = 30 ms) let the
+    // power management settle, and the clock column then says what each schedule really sustains
+    static const unsigned ticks = getenv("UBENCH_TICKS") ? (unsigned)atol(getenv("UBENCH_TICKS")) : 30000u;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, dev, 2000u);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, dev, 30000u);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, dev, ticks);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h.data(), dev, sizeof(unsigned long long) * nw * 4, hipMemcpyDeviceToHost);
     double bodies = 0, cyc = 0;
@@ -311,8 +315,10 @@ static void run(const char *name, Kern kern, int cus, double units_per_body, int
         bodies += (double)h[4 * i]; cyc += (double)h[4 * i + 1];
         first = first < h[4 * i + 3] ? first : h[4 * i + 3]; last = last > h[4 * i + 3] ? last : h[4 * i + 3];
     }
-    printf("%%-58s vgpr %%3d waves/SIMD %%d  %%7.2f SIMD cycles per interaction%%s\n", name, nreg, occ,
-           cus * 4.0 * (cyc / nw) / (bodies * units_per_body), (last - first) > 500 ? " (!)" : "");
+    const double cycles_per_unit = cus * 4.0 * (cyc / nw) / (bodies * units_per_body);
+    const double clock_ghz = (cyc / nw) / ((double)ticks * 10.0);  // shader cycles per 10 ns tick
+    printf("%%-58s vgpr %%3d waves/SIMD %%d  %%7.2f SIMD cycles per interaction  %%5.3f GHz  %%6.2f ns%%s\n", name, nreg, occ,
+           cycles_per_unit, clock_ghz, cycles_per_unit / clock_ghz, (last - first) > 500 ? " (!)" : "");
 }
 int main()
 {
