@@ -187,7 +187,8 @@ int nbody_set_particle_softening(nbody_ctx *ctx, const float *d_eps);
 int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);
 
 /* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default = 4, the kernel
- * with the hand-allocated inner loop; -4 = four rows with the compiler-allocated loop).  Never changes a result bit. */
+ * with the hand-allocated, packed-fp32 inner loop; 40 = the same with one row per instruction; -4 = four rows with the
+ * compiler-allocated loop).  Never changes a result bit. */
 int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
 
 /* Device facts for the roofline: out = {compute units, max clock MHz, wavefront size, LDS bytes per CU}. */

@@ -521,8 +521,8 @@ int nbody_upload_particle_softening(nbody_ctx *c, const float *h_eps)
 
 int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
 {
-    if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == -4 || rpl == 8))
-        return fail(c, NBODY_ERR_INVALID, "nbody_set_rows_per_lane: expected 0, 1, 2, 4, 8 or -4");
+    if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == -4 || rpl == 8 || rpl == 40))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_rows_per_lane: expected 0, 1, 2, 4, 8, -4 or 40");
     c->rows_per_lane = rpl;
     return NBODY_OK;
 }

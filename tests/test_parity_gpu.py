@@ -179,7 +179,7 @@ def test_reference_constants_and_padding(nb, oracle_mod, mode):
 def test_register_blocking_is_bit_exact(nb):
     pos, vel = nb.plummer(10000, seed=31)
     ref = None
-    for rpl in (1, 2, 4, -4, 8):      # 4 = the hand-allocated inner loop, -4 = the compiled one
+    for rpl in (1, 2, 4, 40, -4, 8):  # 4 = hand-allocated packed-fp32 loop, 40 = one row per instruction, -4 = compiled
         with nb.NBodySystem(pos.shape[0]) as s:
             s.set_rows_per_lane(rpl)
             s.setParticlesPosition(pos)
