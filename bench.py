@@ -39,7 +39,7 @@ FLOP_PER_INTERACTION = 20.0        # SURVEY.md 8d (GPU Gems 3 ch.31 convention)
 # flop the instructions of one pair evaluation really perform (= what rocprofv3's SQ_INSTS_VALU_*_F32 counters add up to)
 FLOP_INSTRUCTIONS = {"one_sided": 19.0,   # 3 sub, 6 fma, 3 mul, 1 rsq
                      "pair_once": 26.0}   # 3 sub, 9 fma, 4 mul, 1 rsq, for the two interactions of the pair
-KERNEL_NAME = {"one_sided": "nbody::force_kernel_r4", "pair_once": "nbody::force_sym_kernel"}
+KERNEL_NAME = {"one_sided": "nbody::force_kernel_r4pk", "pair_once": "nbody::force_sym_kernel"}
 PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md, chip-level parameters: 256 CU x 4 SIMD x 32 lanes x 2 x 2.4 GHz
 
 

@@ -65,7 +65,10 @@ def main(tag, rnd, n, kern="force_kernel", mode=""):
             out["simd_cycles_per_interaction"] = cyc * 1024.0 / inter
     if all(k in mean for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")) and durations:
         # wave64 instructions x 64 lanes; an FMA is 2 flop, everything else 1 (v_sub_f32 is counted with the adds)
-        flop = 64.0 * (mean["SQ_INSTS_VALU_ADD_F32"] + mean["SQ_INSTS_VALU_MUL_F32"] + 2.0 * mean["SQ_INSTS_VALU_FMA_F32"] +
+        # force_kernel_r4pk does all its adds, multiplies and FMAs as v_pk_*_f32: the counters see one instruction for two
+        # lanes' worth (7.1 VALU instructions per interaction instead of 13.1), so each counts double
+        pk = 2.0 if "r4pk" in kern else 1.0
+        flop = 64.0 * (pk * (mean["SQ_INSTS_VALU_ADD_F32"] + mean["SQ_INSTS_VALU_MUL_F32"] + 2.0 * mean["SQ_INSTS_VALU_FMA_F32"]) +
                        mean["SQ_INSTS_VALU_TRANS_F32"])
         out["rocprof_flop_per_launch"] = flop
         out["rocprof_TFLOPs"] = flop / (out["avg_launch_ms_kernel_trace"] * 1e-3) / 1e12
