@@ -7,6 +7,7 @@
 //   nbody_run --plummer 65536 --steps 100 --dt 1e-3 --softening 1e-3 --energy-every 10
 //   nbody_run --file galaxy.bin --steps 1000 --dump-every 100 --dump-prefix out/gal
 //   nbody_run --resume out/gal_000500.nbs --steps 500
+//   nbody_run --plummer 1048576 --devices 0,1,2,3,4,5,6,7 --pair-once --steps 10     rows sharded over 8 GPUs, RCCL inside
 //
 // Build: g++ -O2 -std=c++17 -Iinclude host/nbody_run.cpp -Ln_body_problem_amd -lnbody_amd -Wl,-rpath,'$ORIGIN/../n_body_problem_amd'
 #include "../include/nbody.hpp"
@@ -14,13 +15,16 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <algorithm>
 #include <iostream>
+#include <sstream>
 
 static void usage()
 {
     std::cerr << "usage: nbody_run [dataset_id 0-5] [--data-dir DIR] [--file PATH] [--plummer N] [--seed S] [--resume SNAPSHOT]\n"
                  "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P]\n"
-                 "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once] [--particle-softening]\n";
+                 "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once] [--particle-softening]\n"
+                 "                 [--devices D0,D1,...] [--ring] [--peer-copy]      rows sharded over several GPUs (library-owned exchange)\n";
 }
 
 int main(int argc, char **argv)
@@ -30,7 +34,8 @@ int main(int argc, char **argv)
     std::int64_t plummer_n = 0, steps = 100, energy_every = 0, dump_every = 0;
     std::uint64_t seed = 0x5EED0003ull;
     float dt = nbody::kTimeTick, softening = nbody::kSofteningVersion3;  // the reference's constants
-    bool pad = false, kdk = false, pair_once = false, particle_eps = false;
+    bool pad = false, kdk = false, pair_once = false, particle_eps = false, ring = false, peer_copy = false;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
@@ -51,6 +56,12 @@ int main(int argc, char **argv)
         else if (a == "--pair-once") pair_once = true;
         else if (a == "--particle-softening") particle_eps = true;
         else if (a == "--device") device = std::atoi(next().c_str());
+        else if (a == "--devices") {
+            std::stringstream list(next());
+            for (std::string tok; std::getline(list, tok, ',');) devices.push_back(std::atoi(tok.c_str()));
+        }
+        else if (a == "--ring") ring = true;
+        else if (a == "--peer-copy") peer_copy = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-') {
             dataset = std::atoi(a.c_str());  // kernel.cu:1069-1086: argv[1] = dataset id, 0..5
@@ -69,6 +80,58 @@ int main(int argc, char **argv)
         if (pad) nbody_io::pad_reference_style(b);  // accepted, never required (kernel.cu:260-278)
         std::printf("num of Bodies = %lld (real %lld)  dt = %g  softening = %g\n", (long long)b.n(), (long long)n_real, dt, softening);
 
+        if (!devices.empty()) {  // rows sharded over the listed GPUs; everything per step happens inside the library
+            nbody::MultiSystem ms;
+            ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy);
+            ms.setState(b.pos.data(), b.vel.data());
+            ms.timing(true);
+            if (particle_eps) {
+                std::vector<float> eps((size_t)b.n());
+                for (std::int64_t i = 0; i < b.n(); ++i) eps[(size_t)i] = b.vel[4 * (size_t)i + 3];
+                ms.setParticleSoftening(eps.data());
+            }
+            auto inf = ms.info();
+            std::printf("ranks = %lld (RCCL communicator of %lld)  padded bodies = %lld  rows per rank = %lld  split = %lld\n",
+                        (long long)inf[4], (long long)inf[6], (long long)inf[1], (long long)inf[2], (long long)inf[3]);
+            nbody::System::Energy e0{};
+            if (energy_every > 0) {
+                e0 = ms.energy(softening);
+                std::printf("step %lld  E = %.9e (K %.6e U %.6e)\n", (long long)step0, e0.total, e0.kinetic, e0.potential);
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            std::int64_t s = 0;
+            while (s < steps) {  // steps between two reports are enqueued back to back: the exchange stays in flight
+                std::int64_t k = steps - s;
+                if (energy_every > 0) k = std::min(k, energy_every - s % energy_every);
+                if (dump_every > 0) k = std::min(k, dump_every - s % dump_every);
+                ms.stepN((int)k, dt, softening);
+                s += k;
+                const std::int64_t gs = step0 + s;
+                if (energy_every > 0 && (s % energy_every == 0 || s == steps)) {
+                    auto e = ms.energy(softening);
+                    auto p = ms.momentum();
+                    std::printf("step %lld  E = %.9e  dE/E0 = %+.3e  |p| = %.3e\n", (long long)gs, e.total,
+                                (e.total - e0.total) / std::fabs(e0.total), std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+                }
+                if (dump_every > 0 && s % dump_every == 0) {
+                    ms.download(b.pos.data(), b.vel.data());
+                    char name[512];
+                    std::snprintf(name, sizeof name, "%s_%06lld.nbs", dump_prefix.c_str(), (long long)gs);
+                    nbody_io::save_snapshot(name, b, gs, time0 + (double)s * dt);
+                }
+            }
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            auto tm = ms.readTiming();
+            const double inter = (double)b.n() * (double)b.n() * (double)steps;
+            std::printf("%lld steps in %.3f s: %.3f ms/step, %.3e interactions/s (rank 0: force kernels %.3f ms/step, update %.3f ms/step); "
+                        "replicas identical: %s\n", (long long)steps, wall, 1e3 * wall / (double)steps, inter / wall,
+                        tm.forceMs / (double)steps, tm.updateMs / (double)steps, ms.replicasIdentical() ? "yes" : "NO");
+            if (!final_path.empty()) {
+                ms.download(b.pos.data(), b.vel.data());
+                nbody_io::save_snapshot(final_path, b, step0 + steps, time0 + (double)steps * dt);
+            }
+            return 0;
+        }
         nbody::System sys;
         if (pair_once) sys.initializeShard(b.n(), 0, b.n(), nbody_pair_once_split_len(b.n()), device);
         else sys.initialize(b.n(), device);             // initialize(numBodies)

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 1
+#define NBODY_ABI_VERSION 2
+#define NBODY_MIN_SOFTENING 1.0e-9f
 
 typedef struct nbody_ctx nbody_ctx;
 
@@ -88,7 +89,9 @@ float *nbody_velocities_device(nbody_ctx *ctx);
  * dt               : TIME_TICK (kernel.cu:63; the reference uses 0.008).
  * softening        : eps, a length; eps^2 replaces EPSILON (kernel.cu:66).  The reference's VERSION 3
  *                    corresponds to 1e-2 and VERSIONs 1/2 to 1e-3.  0 is allowed: pairs
- *                    at zero distance (the self pair included) then contribute nothing.
+ *                    at zero distance (the self pair included) then contribute nothing, whatever their
+ *                    masses.  0 < softening < NBODY_MIN_SOFTENING is rejected (NBODY_ERR_INVALID): eps^-3 x mass
+ *                    of the self pair would overflow fp32 and poison every sum with 0 x inf.
  * nbody_step returns after the device work is complete (the reference synchronises at kernel.cu:1232,1236);
  * nbody_step_async only enqueues on the context's stream; nbody_sync waits and reports kernel errors. */
 int nbody_step(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, const float *d_masses, float dt,
@@ -146,6 +149,10 @@ int nbody_momentum(nbody_ctx *ctx, const float *d_positions_xyzm, const float *d
  * With timing on, every force / update launch is bracketed by events.  nbody_timing_read synchronises,
  * returns the accumulated milliseconds and launch counts since the last read, and resets them. */
 int nbody_timing_enable(nbody_ctx *ctx, int on);
+/* out6 = {force_ms, force launches, update_ms, update launches, diagonal-tile ms, diagonal-tile launches}: the totals are
+ * SUMS of per-launch durations (launches that overlap on two streams each count in full), not wall time; the pair-once
+ * mode's diagonal-tile kernel is kept apart from the dominant tile kernel.  Waits for every recorded launch. */
+int nbody_timing_read_ex(nbody_ctx *ctx, double *out6);
 int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches, double *update_ms,
                       int64_t *update_launches);
 
@@ -193,6 +200,80 @@ int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
 
 /* Device facts for the roofline: out = {compute units, max clock MHz, wavefront size, LDS bytes per CU}. */
 int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);
+
+/* ======== multi-GPU: rows sharded over the GPUs of one node, the exchange owned by the library ========
+ * The reference is single-GPU (kernel.cu:1225-1242: one device, the default stream), so nothing here replaces a
+ * reference interface: it is the same bracket -- step(positions, velocities, masses, dt, softening) -- for a body set
+ * whose rows are dealt to P GPUs (SURVEY.md 8b "ownership"/"threading", 8e).  A nbody_multi owns per local rank one shard
+ * context, a full replica of the positions, the rank's velocity rows, two compute streams, a communication stream and
+ * one RCCL communicator; nbody_multi_step is the whole step (csrc/nbody_multi.hip):
+ *     own-chunk force launch  ||  all-gather of the previous step's updated rows (in place, RCCL over xGMI)
+ *     complement force launch behind the all-gather, on the second stream
+ *     [pair-once mode: column-side sums, one more all-gather]      update; the next all-gather is issued behind it.
+ * The body count need not divide: the system is padded with zero-mass bodies at the origin (the reference's own padding
+ * device, kernel.cu:265-277) to n_padded = P x rows_per_rank, rows_per_rank whole splits (whole split groups in the
+ * pair-once mode, which therefore shards over 1, 2, 4 or 8 ranks).  The state is bit-identical to ONE context on the
+ * same padded system for any P, exchange and transport.
+ * Process models: nbody_multi_create -- every rank in this process, driven from the calling host thread (RCCL calls of
+ * the local ranks fused with ncclGroupStart/End); nbody_multi_create_rank -- one rank per process (the launch model of
+ * torchrun / mpirun): rank 0 calls nbody_multi_unique_id and the caller hands the 128 bytes to every rank by any
+ * channel it has.  Failure detection: RCCL's asynchronous error state is polled after every step and inside every
+ * wait; a wait longer than the timeout (default 1800 s, NBODY_EXCHANGE_TIMEOUT_S or nbody_multi_set_timeout) aborts the
+ * communicators and returns NBODY_ERR_DEVICE instead of hanging on a dead peer. */
+typedef struct nbody_multi nbody_multi;
+#define NBODY_UNIQUE_ID_BYTES 128
+enum { NBODY_EXCHANGE_ALLGATHER = 0, /* one ncclAllGather per step */
+       NBODY_EXCHANGE_RING = 1 };     /* P-1 ncclSend/ncclRecv hops, the force launch of chunk rank-h starts as hop h lands */
+enum { NBODY_TRANSPORT_RCCL = 0,
+       NBODY_TRANSPORT_PEER_COPY = 1 }; /* hipMemcpyPeerAsync between the replicas: single process only; also the way two
+                                           shards on ONE device are run (RCCL refuses duplicate devices) */
+typedef struct nbody_multi_config {
+    int64_t n_bodies;  /* real bodies */
+    int64_t split_len; /* 0 = nbody_default_split_len / nbody_pair_once_split_len of n_bodies */
+    int force_mode;    /* NBODY_FORCE_ONE_SIDED | NBODY_FORCE_SYMMETRIC */
+    int integrator;    /* NBODY_INTEGRATOR_KICK_DRIFT | NBODY_INTEGRATOR_KDK */
+    int exchange;      /* NBODY_EXCHANGE_* */
+    int transport;     /* NBODY_TRANSPORT_* */
+} nbody_multi_config;
+
+/* Pure host functions (no device needed): the padded size and rows per rank, and hop `hop` (1..P-1) of the ring. */
+int nbody_multi_geometry(int64_t n_bodies, int world_size, int force_mode, int64_t split_len, int64_t *n_padded,
+                         int64_t *rows_per_rank, int64_t *split_len_out);
+int nbody_multi_ring_schedule(int rank, int world_size, int hop, int *send_chunk, int *recv_chunk);
+
+int nbody_multi_unique_id(void *id128); /* ncclGetUniqueId into NBODY_UNIQUE_ID_BYTES bytes */
+int nbody_multi_create(nbody_multi **out, const nbody_multi_config *cfg, const int *devices, int n_devices);
+int nbody_multi_create_rank(nbody_multi **out, const nbody_multi_config *cfg, int device, int rank, int world_size,
+                            const void *unique_id128);
+int nbody_multi_destroy(nbody_multi *m);
+const char *nbody_multi_last_error(const nbody_multi *m); /* m == NULL: last error of a failed create */
+int nbody_multi_set_timeout(nbody_multi *m, double seconds);
+
+/* Host arrays of n_bodies float4 each (setParticlesPosition / setParticlesVelocity, kernel.cu:163-188): every local
+ * rank's replica and velocity rows are filled.  download: all n_bodies rows on every process (either pointer may be
+ * NULL).  set_particle_softening: n_bodies host floats or NULL. */
+int nbody_multi_set_state(nbody_multi *m, const float *host_xyzm, const float *host_xyzw);
+int nbody_multi_set_particle_softening(nbody_multi *m, const float *host_eps);
+int nbody_multi_download(nbody_multi *m, float *host_xyzm, float *host_xyzw);
+
+/* The step.  nbody_multi_step / _step_n return with every replica current and all device work complete;
+ * nbody_multi_step_async only enqueues (the exchange of the updated rows stays in flight under the next step). */
+int nbody_multi_step(nbody_multi *m, float dt, float softening);
+int nbody_multi_step_n(nbody_multi *m, int k, float dt, float softening);
+int nbody_multi_step_async(nbody_multi *m, float dt, float softening);
+int nbody_multi_sync(nbody_multi *m);
+
+/* Diagnostics of the WHOLE system, the same values on every process.  replica_checksums: out2 = {smallest, largest}
+ * checksum of the position replicas over all ranks -- equal when every rank holds the same bits. */
+int nbody_multi_energy(nbody_multi *m, float softening, double *out3);
+int nbody_multi_momentum(nbody_multi *m, double *out4);
+int nbody_multi_replica_checksums(nbody_multi *m, uint64_t *out2);
+/* out8 = {n_bodies, n_padded, rows_per_rank, split_len, world_size, local ranks, ranks of the RCCL communicator, exchange} */
+int nbody_multi_info(const nbody_multi *m, int64_t *out8);
+/* Local rank i's shard context (timing, device info, kernel selection) and device buffers; borrowed. */
+nbody_ctx *nbody_multi_shard(nbody_multi *m, int local_index);
+float *nbody_multi_positions_device(nbody_multi *m, int local_index);
+float *nbody_multi_velocities_device(nbody_multi *m, int local_index);
 
 #ifdef __cplusplus
 }

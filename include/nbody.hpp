@@ -120,4 +120,87 @@ private:
     std::int64_t n_ = 0;
 };
 
+// The same host interface for a body set whose rows are sharded over several GPUs of one node, driven from this one
+// host thread (nbody_multi_create: one RCCL communicator per device, the exchange inside the library).
+class MultiSystem {
+public:
+    MultiSystem() = default;
+    MultiSystem(const MultiSystem &) = delete;
+    MultiSystem &operator=(const MultiSystem &) = delete;
+    ~MultiSystem() { nbody_multi_destroy(m_); }
+
+    // initialize(numBodies) on the given devices; pairOnce / kickDriftKick / ring / peerCopy select the variants
+    void initialize(std::int64_t numBodies, const std::vector<int> &devices, bool pairOnce = false, bool kickDriftKick = false,
+                    bool ring = false, bool peerCopy = false, std::int64_t splitLen = 0)
+    {
+        nbody_multi_destroy(m_);
+        m_ = nullptr;
+        nbody_multi_config cfg{};
+        cfg.n_bodies = numBodies;
+        cfg.split_len = splitLen;
+        cfg.force_mode = pairOnce ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED;
+        cfg.integrator = kickDriftKick ? NBODY_INTEGRATOR_KDK : NBODY_INTEGRATOR_KICK_DRIFT;
+        cfg.exchange = ring ? NBODY_EXCHANGE_RING : NBODY_EXCHANGE_ALLGATHER;
+        cfg.transport = peerCopy ? NBODY_TRANSPORT_PEER_COPY : NBODY_TRANSPORT_RCCL;
+        check(nbody_multi_create(&m_, &cfg, devices.data(), (int)devices.size()), "nbody_multi_create");
+        n_ = numBodies;
+    }
+    void setState(const float *xyzm, const float *xyzw) { check(nbody_multi_set_state(m_, xyzm, xyzw), "nbody_multi_set_state"); }
+    void setParticleSoftening(const float *hostEps)
+    {
+        check(nbody_multi_set_particle_softening(m_, hostEps), "nbody_multi_set_particle_softening");
+    }
+    void download(float *xyzm, float *xyzw) { check(nbody_multi_download(m_, xyzm, xyzw), "nbody_multi_download"); }
+    void step(float dt = kTimeTick, float softening = kSofteningVersion3) { check(nbody_multi_step(m_, dt, softening), "nbody_multi_step"); }
+    void stepN(int k, float dt, float softening) { check(nbody_multi_step_n(m_, k, dt, softening), "nbody_multi_step_n"); }
+    System::Energy energy(float softening)
+    {
+        double e[3];
+        check(nbody_multi_energy(m_, softening, e), "nbody_multi_energy");
+        return {e[0], e[1], e[2]};
+    }
+    std::vector<double> momentum()
+    {
+        std::vector<double> p(4);
+        check(nbody_multi_momentum(m_, p.data()), "nbody_multi_momentum");
+        return p;
+    }
+    bool replicasIdentical()
+    {
+        std::uint64_t c[2];
+        check(nbody_multi_replica_checksums(m_, c), "nbody_multi_replica_checksums");
+        return c[0] == c[1];
+    }
+    void timing(bool on)
+    {
+        for (int i = 0; nbody_multi_shard(m_, i); ++i)
+            nbody_timing_enable(nbody_multi_shard(m_, i), on ? 1 : 0);
+    }
+    // sums of per-launch durations of local rank 0's kernels since the last read
+    System::Timing readTiming()
+    {
+        System::Timing t{};
+        if (nbody_timing_read(nbody_multi_shard(m_, 0), &t.forceMs, &t.forceLaunches, &t.updateMs, &t.updateLaunches) != NBODY_OK)
+            throw std::runtime_error("nbody_timing_read failed");
+        return t;
+    }
+    std::vector<std::int64_t> info()
+    {
+        std::vector<std::int64_t> v(8);
+        check(nbody_multi_info(m_, v.data()), "nbody_multi_info");
+        return v;
+    }
+    std::int64_t numBodies() const { return n_; }
+    nbody_multi *handle() { return m_; }
+
+private:
+    void check(int status, const char *what)
+    {
+        if (status != NBODY_OK)
+            throw std::runtime_error(std::string(what) + ": " + nbody_multi_last_error(m_) + " (" + nbody_status_string(status) + ")");
+    }
+    nbody_multi *m_ = nullptr;
+    std::int64_t n_ = 0;
+};
+
 }  // namespace nbody

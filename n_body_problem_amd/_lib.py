@@ -61,6 +61,7 @@ _PROTOTYPES = {
     "nbody_timing_enable": (c_int, [c_void_p, c_int]),
     "nbody_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
                                   POINTER(c_int64)]),
+    "nbody_timing_read_ex": (c_int, [c_void_p, POINTER(c_double)]),
     "nbody_set_force_mode": (c_int, [c_void_p, c_int]),
     "nbody_pair_once_split_len": (ctypes.c_int64, [ctypes.c_int64]),
     "nbody_sym_set_colparts": (c_int, [c_void_p, c_void_p]),
@@ -71,7 +72,36 @@ _PROTOTYPES = {
     "nbody_upload_particle_softening": (c_int, [c_void_p, c_void_p]),
     "nbody_set_rows_per_lane": (c_int, [c_void_p, c_int]),
     "nbody_device_info": (c_int, [c_void_p, POINTER(c_int64), c_char_p, c_int]),
+    # multi-GPU (csrc/nbody_multi.hip)
+    "nbody_multi_geometry": (c_int, [c_int64, c_int, c_int, c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "nbody_multi_ring_schedule": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "nbody_multi_unique_id": (c_int, [c_void_p]),
+    "nbody_multi_create": (c_int, [POINTER(c_void_p), c_void_p, POINTER(c_int), c_int]),
+    "nbody_multi_create_rank": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p]),
+    "nbody_multi_destroy": (c_int, [c_void_p]),
+    "nbody_multi_last_error": (c_char_p, [c_void_p]),
+    "nbody_multi_set_timeout": (c_int, [c_void_p, c_double]),
+    "nbody_multi_set_state": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nbody_multi_set_particle_softening": (c_int, [c_void_p, c_void_p]),
+    "nbody_multi_download": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nbody_multi_step": (c_int, [c_void_p, c_float, c_float]),
+    "nbody_multi_step_n": (c_int, [c_void_p, c_int, c_float, c_float]),
+    "nbody_multi_step_async": (c_int, [c_void_p, c_float, c_float]),
+    "nbody_multi_sync": (c_int, [c_void_p]),
+    "nbody_multi_energy": (c_int, [c_void_p, c_float, POINTER(c_double)]),
+    "nbody_multi_momentum": (c_int, [c_void_p, POINTER(c_double)]),
+    "nbody_multi_replica_checksums": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
+    "nbody_multi_info": (c_int, [c_void_p, POINTER(c_int64)]),
+    "nbody_multi_shard": (c_void_p, [c_void_p, c_int]),
+    "nbody_multi_positions_device": (c_void_p, [c_void_p, c_int]),
+    "nbody_multi_velocities_device": (c_void_p, [c_void_p, c_int]),
 }
+
+
+class MultiConfig(ctypes.Structure):
+    """``nbody_multi_config`` of include/nbody.h."""
+    _fields_ = [("n_bodies", c_int64), ("split_len", c_int64), ("force_mode", c_int), ("integrator", c_int),
+                ("exchange", c_int), ("transport", c_int)]
 
 _lib = None
 

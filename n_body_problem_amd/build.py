@@ -1,8 +1,8 @@
 """Build recipe of ``libnbody_amd.so`` (HIP kernels + C ABI) for gfx950, in-tree.
 
 ``hipcc`` cross-compiles without a GPU, so this runs in the build container as well as on the
-MI355X box.  The library links only ``libamdhip64``: no torch types cross the ABI
-(``include/nbody.h``).
+MI355X box.  The library links ``libamdhip64`` and ``librccl`` (the multi-GPU exchange of
+``csrc/nbody_multi.hip``): no torch types cross the ABI (``include/nbody.h``).
 """
 from __future__ import annotations
 
@@ -13,7 +13,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnbody_amd.so")
-SOURCES = ["nbody_kernels.hip", "nbody_symmetric.hip", "nbody_capi.hip"]
+SOURCES = ["nbody_kernels.hip", "nbody_symmetric.hip", "nbody_capi.hip", "nbody_multi.hip"]
 HEADERS = [os.path.join(CSRC, "nbody_kernels.h"), os.path.join(PKG_DIR, "..", "include", "nbody.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ffp-contract=off",
@@ -58,7 +58,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed compiling {src}:\n" + res.stderr[-4000:])
         objs.append(obj)
-    cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB_PATH]
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib")
+    cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-L" + rocm_lib, "-lrccl", "-o", LIB_PATH]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))

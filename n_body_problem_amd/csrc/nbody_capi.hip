@@ -47,10 +47,10 @@ struct nbody_ctx {
     std::vector<double> reduce_host;
     std::vector<unsigned char> split_done;  // which splits nbody_forces has produced since the last update
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_force, ev_update;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_force, ev_update, ev_aux;  // launches not yet added to the totals
     std::vector<hipEvent_t> ev_pool;
-    double force_ms = 0, update_ms = 0;
-    int64_t force_launches = 0, update_launches = 0;
+    double force_ms = 0, update_ms = 0, aux_ms = 0;  // aux: the pair-once mode's diagonal-tile launches
+    int64_t force_launches = 0, update_launches = 0, aux_launches = 0;
     std::string err;
 };
 
@@ -207,6 +207,7 @@ int nbody_destroy(nbody_ctx *c)
         (void)hipStreamSynchronize(c->own_stream);
     for (auto &p : c->ev_force) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : c->ev_update) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : c->ev_aux) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->partials) (void)hipFree(c->partials);
     if (c->pos) (void)hipFree(c->pos);
@@ -316,16 +317,52 @@ static hipError_t get_event(nbody_ctx *c, hipEvent_t *e)
     return hipEventCreate(e);
 }
 
+typedef std::vector<std::pair<hipEvent_t, hipEvent_t>> EventPairs;
+
+// Adds the finished launches at the head of the list to the totals and returns their events to the pool (all of them,
+// waiting for each stop event, when `wait`): a long run with timing on holds a bounded number of live events.
+static int drain(nbody_ctx *c, EventPairs &l, double &ms, int64_t &n, bool wait)
+{
+    size_t done = 0;
+    for (; done < l.size(); ++done) {
+        auto &p = l[done];
+        if (wait)
+            HIP_TRY(c, hipEventSynchronize(p.second));  // whichever stream the launch ran on
+        else if (hipEventQuery(p.second) != hipSuccess)
+            break;
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, p.first, p.second));
+        ms += t;
+        ++n;
+        c->ev_pool.push_back(p.first);
+        c->ev_pool.push_back(p.second);
+    }
+    l.erase(l.begin(), l.begin() + (ptrdiff_t)done);
+    return NBODY_OK;
+}
+
 struct TimedLaunch {
     nbody_ctx *c;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
+    EventPairs *list;
+    double *ms;
+    int64_t *count;
     hipEvent_t a = nullptr, b = nullptr;
-    TimedLaunch(nbody_ctx *ctx, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : c(ctx), list(l)
+    TimedLaunch(nbody_ctx *ctx, EventPairs *l, double *total_ms, int64_t *launches) : c(ctx), list(l), ms(total_ms), count(launches)
     {
-        if (c->timing && get_event(c, &a) == hipSuccess && get_event(c, &b) == hipSuccess)
-            (void)hipEventRecord(a, c->stream);
-        else
+        if (!c->timing)
+            return;
+        if (list->size() >= 64)
+            (void)drain(c, *list, *ms, *count, false);
+        if (get_event(c, &a) != hipSuccess) {
+            a = nullptr;
+            return;
+        }
+        if (get_event(c, &b) != hipSuccess) {
+            c->ev_pool.push_back(a);
             a = b = nullptr;
+            return;
+        }
+        (void)hipEventRecord(a, c->stream);
     }
     ~TimedLaunch()
     {
@@ -344,38 +381,40 @@ int nbody_timing_enable(nbody_ctx *c, int on)
     return NBODY_OK;
 }
 
-static int drain(nbody_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &l, double &ms, int64_t &n)
+int nbody_timing_read_ex(nbody_ctx *c, double *out6)
 {
-    for (auto &p : l) {
-        float t = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&t, p.first, p.second));
-        ms += t;
-        ++n;
-        c->ev_pool.push_back(p.first);
-        c->ev_pool.push_back(p.second);
-    }
-    l.clear();
+    if (!c || !out6)
+        return NBODY_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = drain(c, c->ev_force, c->force_ms, c->force_launches, true);
+    if (rc == NBODY_OK)
+        rc = drain(c, c->ev_update, c->update_ms, c->update_launches, true);
+    if (rc == NBODY_OK)
+        rc = drain(c, c->ev_aux, c->aux_ms, c->aux_launches, true);
+    if (rc != NBODY_OK)
+        return rc;
+    out6[0] = c->force_ms;
+    out6[1] = (double)c->force_launches;
+    out6[2] = c->update_ms;
+    out6[3] = (double)c->update_launches;
+    out6[4] = c->aux_ms;
+    out6[5] = (double)c->aux_launches;
+    c->force_ms = c->update_ms = c->aux_ms = 0;
+    c->force_launches = c->update_launches = c->aux_launches = 0;
     return NBODY_OK;
 }
 
 int nbody_timing_read(nbody_ctx *c, double *force_ms, int64_t *force_launches, double *update_ms,
                       int64_t *update_launches)
 {
-    if (!c)
-        return NBODY_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int rc = drain(c, c->ev_force, c->force_ms, c->force_launches);
-    if (rc == NBODY_OK)
-        rc = drain(c, c->ev_update, c->update_ms, c->update_launches);
+    double v[6];
+    int rc = nbody_timing_read_ex(c, v);
     if (rc != NBODY_OK)
         return rc;
-    if (force_ms) *force_ms = c->force_ms;
-    if (force_launches) *force_launches = c->force_launches;
-    if (update_ms) *update_ms = c->update_ms;
-    if (update_launches) *update_launches = c->update_launches;
-    c->force_ms = c->update_ms = 0;
-    c->force_launches = c->update_launches = 0;
+    if (force_ms) *force_ms = v[0];
+    if (force_launches) *force_launches = (int64_t)v[1];
+    if (update_ms) *update_ms = v[2];
+    if (update_launches) *update_launches = (int64_t)v[3];
     return NBODY_OK;
 }
 
@@ -394,6 +433,10 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         const int gs = std::max(1, (c->n_splits + kSymGroups - 1) / kSymGroups);
         const int split_lo = (int)(c->row_lo / c->split_len);
         const int split_hi = (int)((c->row_lo + c->row_count + c->split_len - 1) / c->split_len);
+        const int64_t row_hi = c->row_lo + c->row_count;
+        if (c->row_count && row_hi % c->split_len != 0 && row_hi != c->n_total)
+            return fail(c, NBODY_ERR_INVALID, "nbody_set_force_mode: in the pair-once mode a context's rows must end on a split "
+                                              "boundary or at n_total (a tile's row side is a whole split)");
         if (c->row_count && (split_lo % gs != 0 || (split_hi % gs != 0 && split_hi != c->n_splits)))
             return fail(c, NBODY_ERR_INVALID,
                         "nbody_set_force_mode: in the pair-once mode a context's rows must be whole groups of " +
@@ -575,6 +618,9 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return fail(c, NBODY_ERR_INVALID, std::string(who) + ": NULL argument");
     if (!(softening >= 0.f) || !std::isfinite(softening))
         return fail(c, NBODY_ERR_INVALID, std::string(who) + ": softening must be finite and >= 0");
+    if (softening > 0.f && softening < NBODY_MIN_SOFTENING)
+        return fail(c, NBODY_ERR_INVALID, std::string(who) + ": 0 < softening < 1e-9 would overflow fp32 (eps^-3 x mass in the "
+                                                             "self pair); use 0 (zero-distance pairs then contribute nothing)");
     if (col_lo < 0 || col_count < 0 || col_lo + col_count > c->n_total || col_lo % c->split_len != 0 ||
         ((col_lo + col_count) % c->split_len != 0 && col_lo + col_count != c->n_total))
         return fail(c, NBODY_ERR_INVALID, std::string(who) + ": column range must be split-aligned and inside [0,n_total]");
@@ -653,10 +699,13 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.eps_pp = c->eps_pp;
         HIP_TRY(c, hipSetDevice(c->device));
         {
-            TimedLaunch t(c, &c->ev_force);  // the dominant kernel alone, so that the time is rocprofv3's for it
+            TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone: rocprofv3's time for it
             HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
         }
-        HIP_TRY(c, launch_forces_symmetric_diag(sa, c->stream));
+        {
+            TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches);  // the diagonal tiles, reported separately
+            HIP_TRY(c, launch_forces_symmetric_diag(sa, c->stream));
+        }
         for (int s = 0; s < c->n_splits; ++s)
             if ((s >= first && s < first + count) != complement)
                 c->split_done[(size_t)s] = 1;
@@ -687,7 +736,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     {
-        TimedLaunch t(c, &c->ev_force);
+        TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);
         HIP_TRY(c, launch_forces(a, pick_rows_per_lane(c, a.split_count), c->stream));
     }
     for (int s = 0; s < c->n_splits; ++s)
@@ -716,7 +765,7 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     {
-        TimedLaunch t(c, &c->ev_update);
+        TimedLaunch t(c, &c->ev_update, &c->update_ms, &c->update_launches);
         const float4 *partials;
         int n_splits;
         int rc = summed_partials(c, "nbody_update", &partials, &n_splits);
@@ -800,7 +849,7 @@ int nbody_kdk_kick_drift(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     {
-        TimedLaunch t(c, &c->ev_update);
+        TimedLaunch t(c, &c->ev_update, &c->update_ms, &c->update_launches);
         HIP_TRY(c, launch_kdk_kick_drift(reinterpret_cast<float4 *>(d_pos), reinterpret_cast<float4 *>(d_vel), c->acc,
                                          (int)c->row_lo, (int)c->row_count, dt, c->stream));
     }
@@ -823,7 +872,7 @@ int nbody_kdk_kick(nbody_ctx *c, float *d_vel, float dt)
         return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     {
-        TimedLaunch t(c, &c->ev_update);
+        TimedLaunch t(c, &c->ev_update, &c->update_ms, &c->update_launches);
         const float4 *partials;
         int n_splits;
         rc = summed_partials(c, "nbody_kdk_kick", &partials, &n_splits);

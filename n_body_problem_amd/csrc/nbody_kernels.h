@@ -8,6 +8,13 @@ namespace nbody {
 
 constexpr int kTile = 256;  // bodies per LDS tile == threads per workgroup (reference BLOCK_SIZE, kernel.cu:65)
 
+// Zero-distance guard of the eps == 0 kernel variants: a pair whose r^2 is below the smallest normal float (the self
+// pair, coincident bodies) contributes exactly 0 for ANY finite mass -- r^2 is replaced by +inf, so v_rsq_f32 returns 0
+// and every later product is 0 (a clamp of r^2 instead would make m * inv^3 overflow for heavy bodies and 0 * inf = NaN).
+// v_rsq_f32 does not take denormal inputs, hence FLT_MIN rather than 0 as the threshold.  One v_cmp + one v_cndmask.
+constexpr float kGuardMin = 1.17549435e-38f;
+__device__ __forceinline__ float guard_r2(float r2) { return r2 >= kGuardMin ? r2 : __builtin_inff(); }
+
 struct ForceArgs {
     const float4 *pos;   // all n_total bodies {x,y,z,m}
     float4 *partials;    // [n_splits][row_count] partial accelerations {ax,ay,az,unused}

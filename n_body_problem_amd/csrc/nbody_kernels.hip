@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
                 r2 = __builtin_fmaf(dy[k], dy[k], r2);
                 r2 = __builtin_fmaf(dz[k], dz[k], r2);
                 if (GUARD)  // eps == 0: a pair at zero distance (the self pair) must contribute 0, not NaN
-                    r2 = __builtin_fmaxf(r2, 1.0e-24f);
+                    r2 = guard_r2(r2);
                 w[k] = r2;
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -161,14 +161,14 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 // src1 sit in the same bank (register index mod 4) costs two extra cycles, and the compiled loop has four to five
 // such instructions per interaction.  Allocation (bank = index mod 4):
 //   v0-3 / v4-7   column body {x,y,z,m} (banks 0,1,2,3), double-buffered: the next ds_read_b128 travels in the gap
-//   v8            eps^2 (only ever src2)            v35  1e-24 (GUARD only)          v52  LDS byte address
+//   v8            eps^2 (only ever src2)            v35  FLT_MIN, v53 +inf (GUARD only)          v52  LDS byte address
 //   row k=0..3    x,y,z = v(9+4k), v(10+4k), v(11+4k) (banks 1,2,3)   ax = v(12+4k)   ay,az = v(25+2k), v(26+2k)
 //   temps k       r2/inv/s = v(36+4k) (bank 0)   dx,dy,dz = v(37+4k)..v(39+4k) (banks 1,2,3)   inv^2 = v33/v34
 #define NB_PRE(PX, PY, PZ, X, Y, Z, R, D0, D1, D2, GRD)                                                          \
     "v_sub_f32_e32 " D0 ", " PX ", " X "\n\tv_sub_f32_e32 " D1 ", " PY ", " Y "\n\tv_sub_f32_e32 " D2 ", " PZ ", " Z "\n\t" \
     "v_fma_f32 " R ", " D0 ", " D0 ", v8\n\tv_fmac_f32_e32 " R ", " D1 ", " D1 "\n\tv_fmac_f32_e32 " R ", " D2 ", " D2 "\n\t" GRD(R)
 #define NB_NOGUARD(R) ""
-#define NB_GUARD(R) "v_max_f32_e32 " R ", v35, " R "\n\t"
+#define NB_GUARD(R) "v_cmp_le_f32_e32 vcc, v35, " R "\n\tv_cndmask_b32_e32 " R ", v53, " R ", vcc\n\t"
 #define NB_POST(PM, AX, AY, AZ, R, D0, D1, D2, Q)                                                                \
     "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " R ", " PM ", " R "\n\tv_mul_f32_e32 " R ", " R ", " Q "\n\t"     \
     "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t"
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     register float ay2 asm("v29"), az2 asm("v30"), ay3 asm("v31"), az3 asm("v32");
     register float eps2 asm("v8");
     register float tiny asm("v35");
+    register float pinf asm("v53");
     {
         float4 p[4];
 #pragma unroll
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     }
     ax0 = ay0 = az0 = ax1 = ay1 = az1 = ax2 = ay2 = az2 = ax3 = ay3 = az3 = 0.f;
     eps2 = a.eps2;
-    tiny = 1.0e-24f;
+    tiny = kGuardMin;
+    pinf = __builtin_inff();
 
     float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j0 + tid < j1)
@@ -275,9 +277,9 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
         : "+v"(ax0), "+v"(ay0), "+v"(az0), "+v"(ax1), "+v"(ay1), "+v"(az1), "+v"(ax2), "+v"(ay2), "+v"(az2), "+v"(ax3),    \
           "+v"(ay3), "+v"(az3), "+v"(lds), [cnt] "=&s"(cnt)                                                             \
         : "v"(x0), "v"(y0), "v"(z0), "v"(x1), "v"(y1), "v"(z1), "v"(x2), "v"(y2), "v"(z2), "v"(x3), "v"(y3), "v"(z3),      \
-          "v"(eps2), "v"(tiny)                                                                                          \
+          "v"(eps2), "v"(tiny), "v"(pinf)                                                                               \
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42",   \
-          "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "memory"
+          "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "vcc", "memory"
         if (GUARD)
             asm volatile(NB_TILE_LOOP(NB_GUARD) NB_OPERANDS);
         else
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
 // the results bit-identical, and 26 -> 14 issued instructions per 2 interactions measured 2 % less time (259.6 -> 254.6 ms
 // per N = 2^20 pass, same box).  force_kernel_r4 above (rows_per_lane = 40) is kept for the comparison.
 // 64-bit operands sit in even-aligned pairs; pair classes ((reg / 2) mod 2) of src0 and src1 differ in every instruction:
-//   v[0:3] / v[4:7]  column body: (x,y) class 0, (z,m) class 1       v[8:9] = (eps^2, -) class 0    v10 = 1e-24
+//   v[0:3] / v[4:7]  column body: (x,y) class 0, (z,m) class 1       v[8:9] = (eps^2, -) class 0    v10 = FLT_MIN, v11 = +inf (GUARD)
 //   rows 0,1 / 2,3:  X v[14:15] / v[22:23], Y v[18:19] / v[26:27] (class 1), Z v[12:13] / v[16:17] (class 0)
 //   temps:           DX,DY,DZ v[30:31],v[34:35],v[38:39] / v[42:43],v[46:47],v[50:51] (class 1), R v[20:21] / v[24:25] (class 0),
 //                    Q v[54:55] (class 1)          sums: AX,AY,AZ v[28:29],v[32:33],v[36:37] / v[40:41],v[44:45],v[48:49]
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     "v_pk_fma_f32 " R ", " DY ", " DY ", " R "\n\t"                                                                  \
     "v_pk_fma_f32 " R ", " DZ ", " DZ ", " R "\n\t" GRD(RLO) GRD(RHI)
 #define PK_NOGUARD(R) ""
-#define PK_GUARD(R) "v_max_f32_e32 " R ", v10, " R "\n\t"
+#define PK_GUARD(R) "v_cmp_le_f32_e32 vcc, v10, " R "\n\tv_cndmask_b32_e32 " R ", v11, " R ", vcc\n\t"
 #define PK_POST(PZM, AX, AY, AZ, DX, DY, DZ, R)                                                                  \
     "v_pk_mul_f32 v[54:55], " R ", " R "\n\t"                                                                       \
     "v_pk_mul_f32 " R ", " PZM ", " R " op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                           \
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
     const nb_f2 x23 = {p[2].x, p[3].x}, y23 = {p[2].y, p[3].y}, z23 = {p[2].z, p[3].z};
     nb_f2 ax01 = {0.f, 0.f}, ay01 = ax01, az01 = ax01, ax23 = ax01, ay23 = ax01, az23 = ax01;
     const nb_f2 epsv = {a.eps2, 0.f};
-    const float tiny = 1.0e-24f;
+    const float tiny = kGuardMin, pinf = __builtin_inff();
 
     float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j0 + tid < j1)
@@ -400,9 +402,9 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
         : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),          \
           "+{v[48:49]}"(az23), "+{v52}"(lds), [cnt] "=&s"(cnt)                                                            \
         : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23), "{v[16:17]}"(z23),  \
-          "{v[8:9]}"(epsv), "{v10}"(tiny)                                                                                 \
+          "{v[8:9]}"(epsv), "{v10}"(tiny), "{v11}"(pinf)                                                                  \
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35", "v38",   \
-          "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory"
+          "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "vcc", "memory"
         if (GUARD)
             asm volatile(PK_TILE_LOOP(PK_GUARD) PK_OPERANDS);
         else

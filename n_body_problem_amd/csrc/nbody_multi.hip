@@ -1,0 +1,996 @@
+// nbody_multi.hip -- rows sharded over the GPUs of one node, the exchange owned by the library.
+//
+// The reference is single-GPU (main_project/kernel.cu:1225-1242: one device, default stream); SURVEY.md 8b/8e make the
+// multi-GPU step the build's own contract: "ctx owns scratch, replicas, streams, RCCL comms ... multi-GPU driven from one
+// host thread with ncclGroupStart/End (or one thread per device) -- invisible at the ABI".  A nbody_multi owns, per
+// local rank: one shard context (nbody_create_shard), a full replica of the positions, the rank's velocity rows, a
+// compute stream, a second compute stream for the launch that waits for the exchange, a communication stream and one
+// RCCL communicator.  nbody_multi_step is the whole step of every local rank:
+//
+//     own-chunk force launch (needs no remote rows)  ||  all-gather of the previous step's updated rows (RCCL, in place)
+//     complement force launch, ordered after the all-gather, on the second stream (fills the first launch's tail)
+//     pair-once mode: nbody_sym_reduce -> all-gather of the column-side sums (one per step, exposed)
+//     update (kick-drift) or kick (kick-drift-kick); the next all-gather is issued right behind it
+//
+// NBODY_EXCHANGE_RING spells the position all-gather out as P-1 ncclSend/ncclRecv hops with one event per hop; the
+// force launch of chunk (rank - h) starts as hop h lands.  Two process models, one code path: every rank in this
+// process (nbody_multi_create: ncclCommInitAll, collectives of the local ranks fused with ncclGroupStart/End), or one
+// rank per process (nbody_multi_create_rank: ncclCommInitRank with an id the caller distributes).
+// NBODY_TRANSPORT_PEER_COPY (single process only) moves the same slices with hipMemcpyPeerAsync instead of RCCL: RCCL
+// refuses two ranks on one device, so this is also how two shards on ONE GPU are tested against a single context.
+//
+// Failure detection: ncclCommGetAsyncError is polled after every step and inside every wait; a wait
+// that exceeds the timeout aborts the communicators and returns NBODY_ERR_DEVICE instead of hanging on a dead peer.
+//
+// Determinism: chunk boundaries are multiples of split_len (whole split groups in the pair-once mode), so the state is
+// bit-identical to one context on the same padded system for any world size, exchange mode or arrival order.
+#include "../../include/nbody.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Channel {  // one exchange in flight per channel and local rank
+    std::vector<hipEvent_t> ready;  // on the compute stream: the rank's slice is final and it reads nobody else's any more
+    std::vector<hipEvent_t> done;   // on the comm stream: the rank's part of the exchange has been enqueued/has landed
+};
+
+struct Rank {
+    int rank = 0, device = 0;
+    nbody_ctx *ctx = nullptr;
+    float *pos = nullptr;       // replica: n_padded x float4
+    float *vel = nullptr;       // own rows: chunk x float4
+    float *colparts = nullptr;  // pair-once: NBODY_SYM_GROUPS x n_padded x float4
+    hipStream_t compute = nullptr, side = nullptr, comm = nullptr;
+    ncclComm_t nccl = nullptr;
+    hipEvent_t ev_start = nullptr, ev_side = nullptr;
+    std::vector<hipEvent_t> ev_hop;  // ring: hop h has been sent by this rank (PEER) / has landed at this rank (RCCL)
+    unsigned long long *scratch = nullptr;  // 4 x 8 bytes on the device (checksum, all-reduce staging)
+};
+
+}  // namespace
+
+struct nbody_multi {
+    nbody_multi_config cfg{};
+    int world = 1;
+    int64_t n_bodies = 0, n_padded = 0, chunk = 0, split_len = 0;
+    std::vector<Rank> ranks;  // the local ranks
+    Channel ch_pos, ch_col;
+    bool exchange_in_flight = false;  // the position exchange of the last update has been issued and not yet consumed
+    bool kdk_ready = false;
+    bool have_state = false;
+    double timeout_s = 1800.0;
+    float *gather_vel = nullptr;  // multi-process download: all velocities, on the first local device
+    std::string err;
+};
+
+static thread_local std::string g_multi_create_error;
+
+static int mfail(nbody_multi *m, int status, const std::string &msg)
+{
+    if (m)
+        m->err = msg;
+    else
+        g_multi_create_error = msg;
+    return status;
+}
+
+#define MHIP(m, call)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return mfail((m), e_ == hipErrorOutOfMemory ? NBODY_ERR_ALLOC : NBODY_ERR_DEVICE,                  \
+                         std::string(#call) + ": " + hipGetErrorString(e_));                                   \
+    } while (0)
+#define MNCCL(m, call)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t r_ = (call);                                                                              \
+        if (r_ != ncclSuccess && r_ != ncclInProgress)                                                         \
+            return mfail((m), NBODY_ERR_DEVICE, std::string(#call) + ": RCCL: " + ncclGetErrorString(r_));     \
+    } while (0)
+#define MCTX(m, r, call)                                                                                       \
+    do {                                                                                                       \
+        int s_ = (call);                                                                                       \
+        if (s_ != NBODY_OK)                                                                                    \
+            return mfail((m), s_, std::string(#call) + " (rank " + std::to_string((r).rank) + "): " +           \
+                                      nbody_last_error((r).ctx));                                              \
+    } while (0)
+
+__global__ void nbody_checksum_kernel(const unsigned *words, size_t n, unsigned long long *out)
+{
+    unsigned long long s = 0;  // integer sums are associative: the result does not depend on the order of the atomics
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        s += (unsigned long long)words[i] * (unsigned long long)((i & 1023u) + 1u);
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(out, s);
+}
+
+static bool rccl(const nbody_multi *m) { return m->cfg.transport == NBODY_TRANSPORT_RCCL; }
+static bool pair_once(const nbody_multi *m) { return m->cfg.force_mode == NBODY_FORCE_SYMMETRIC; }
+static bool all_local(const nbody_multi *m) { return (int)m->ranks.size() == m->world; }
+
+// ---- pure host helpers (CPU-testable) --------------------------------------------------------------------------
+
+extern "C" int nbody_multi_geometry(int64_t n_bodies, int world_size, int force_mode, int64_t split_len, int64_t *n_padded,
+                                    int64_t *rows_per_rank, int64_t *split_len_out)
+{
+    if (n_bodies < 0 || world_size < 1 || (force_mode != NBODY_FORCE_ONE_SIDED && force_mode != NBODY_FORCE_SYMMETRIC))
+        return NBODY_ERR_INVALID;
+    if (split_len == 0)
+        split_len = force_mode == NBODY_FORCE_SYMMETRIC ? nbody_pair_once_split_len(n_bodies) : nbody_default_split_len(n_bodies);
+    if (split_len <= 0 || split_len % 256 != 0)
+        return NBODY_ERR_INVALID;
+    const int64_t n_splits = n_bodies > 0 ? (n_bodies + split_len - 1) / split_len : 1;
+    int64_t padded, chunk;
+    if (force_mode == NBODY_FORCE_SYMMETRIC) {
+        // the partial sums are added in NBODY_SYM_GROUPS groups of ceil(n_splits / groups) splits; a rank owns whole groups
+        if (NBODY_SYM_GROUPS % world_size != 0)
+            return NBODY_ERR_INVALID;
+        const int64_t group_splits = (n_splits + NBODY_SYM_GROUPS - 1) / NBODY_SYM_GROUPS;
+        padded = NBODY_SYM_GROUPS * group_splits * split_len;
+        chunk = (NBODY_SYM_GROUPS / world_size) * group_splits * split_len;
+    } else {
+        const int64_t splits_per_rank = (n_splits + world_size - 1) / world_size;
+        chunk = splits_per_rank * split_len;
+        padded = chunk * world_size;
+    }
+    if (padded > ((int64_t)1 << 30))
+        return NBODY_ERR_INVALID;
+    if (n_padded) *n_padded = padded;
+    if (rows_per_rank) *rows_per_rank = chunk;
+    if (split_len_out) *split_len_out = split_len;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_ring_schedule(int rank, int world_size, int hop, int *send_chunk, int *recv_chunk)
+{
+    if (world_size < 1 || rank < 0 || rank >= world_size || hop < 1 || hop >= world_size)
+        return NBODY_ERR_INVALID;
+    // hop h: every rank passes on the chunk it received in hop h-1 (its own in hop 1) to rank+1
+    if (send_chunk) *send_chunk = ((rank - hop + 1) % world_size + world_size) % world_size;
+    if (recv_chunk) *recv_chunk = ((rank - hop) % world_size + world_size) % world_size;
+    return NBODY_OK;
+}
+
+extern "C" const char *nbody_multi_last_error(const nbody_multi *m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+
+extern "C" int nbody_multi_unique_id(void *id128)
+{
+    static_assert(sizeof(ncclUniqueId) <= NBODY_UNIQUE_ID_BYTES, "ncclUniqueId does not fit NBODY_UNIQUE_ID_BYTES");
+    if (!id128)
+        return NBODY_ERR_INVALID;
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess)
+        return mfail(nullptr, NBODY_ERR_DEVICE, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memset(id128, 0, NBODY_UNIQUE_ID_BYTES);
+    std::memcpy(id128, &id, sizeof id);
+    return NBODY_OK;
+}
+
+// ---- creation ----------------------------------------------------------------------------------------------------
+
+static int make_events(nbody_multi *m, std::vector<hipEvent_t> &v, size_t n)
+{
+    v.assign(n, nullptr);
+    for (auto &e : v)
+        MHIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return NBODY_OK;
+}
+
+static int setup_ranks(nbody_multi *m)
+{
+    const size_t nl = m->ranks.size();
+    m->ch_pos.ready.assign(nl, nullptr);
+    m->ch_pos.done.assign(nl, nullptr);
+    m->ch_col.ready.assign(nl, nullptr);
+    m->ch_col.done.assign(nl, nullptr);
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        int s = nbody_create_shard(&r.ctx, r.device, m->n_padded, (int64_t)r.rank * m->chunk, m->chunk, m->split_len);
+        if (s != NBODY_OK)
+            return mfail(m, s, std::string("nbody_create_shard: ") + nbody_last_error(nullptr));
+        MCTX(m, r, nbody_set_force_mode(r.ctx, m->cfg.force_mode));
+        MCTX(m, r, nbody_set_integrator(r.ctx, m->cfg.integrator));
+        MHIP(m, hipStreamCreateWithFlags(&r.compute, hipStreamNonBlocking));
+        MHIP(m, hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+        MHIP(m, hipStreamCreateWithFlags(&r.comm, hipStreamNonBlocking));
+        if (m->n_padded) {
+            MHIP(m, hipMalloc((void **)&r.pos, sizeof(float) * 4 * (size_t)m->n_padded));
+            MHIP(m, hipMemsetAsync(r.pos, 0, sizeof(float) * 4 * (size_t)m->n_padded, r.compute));
+            MHIP(m, hipMalloc((void **)&r.vel, sizeof(float) * 4 * (size_t)m->chunk));
+            MHIP(m, hipMemsetAsync(r.vel, 0, sizeof(float) * 4 * (size_t)m->chunk, r.compute));
+        }
+        MHIP(m, hipMalloc((void **)&r.scratch, 4 * sizeof(unsigned long long)));
+        if (pair_once(m) && m->world > 1 && m->n_padded) {
+            MHIP(m, hipMalloc((void **)&r.colparts, sizeof(float) * 4 * (size_t)NBODY_SYM_GROUPS * (size_t)m->n_padded));
+            MCTX(m, r, nbody_sym_set_colparts(r.ctx, r.colparts));
+        }
+        for (hipEvent_t *e : {&r.ev_start, &r.ev_side, &m->ch_pos.ready[i], &m->ch_pos.done[i], &m->ch_col.ready[i],
+                              &m->ch_col.done[i]})
+            MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        int rc = make_events(m, r.ev_hop, (size_t)m->world);
+        if (rc != NBODY_OK)
+            return rc;
+        MHIP(m, hipStreamSynchronize(r.compute));
+    }
+    if (!rccl(m))  // peer copies between distinct devices go over xGMI directly when peer access is on
+        for (Rank &a : m->ranks)
+            for (Rank &b : m->ranks)
+                if (a.device != b.device) {
+                    int can = 0;
+                    if (hipSetDevice(a.device) == hipSuccess && hipDeviceCanAccessPeer(&can, a.device, b.device) == hipSuccess && can)
+                        (void)hipDeviceEnablePeerAccess(b.device, 0);  // "already enabled" is fine
+                    (void)hipGetLastError();
+                }
+    return NBODY_OK;
+}
+
+static int create_common(nbody_multi **out, const nbody_multi_config *cfg, int world, nbody_multi **made)
+{
+    if (!out)
+        return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: out is NULL");
+    *out = nullptr;
+    if (!cfg)
+        return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: config is NULL");
+    if ((cfg->integrator != NBODY_INTEGRATOR_KICK_DRIFT && cfg->integrator != NBODY_INTEGRATOR_KDK) ||
+        (cfg->exchange != NBODY_EXCHANGE_ALLGATHER && cfg->exchange != NBODY_EXCHANGE_RING) ||
+        (cfg->transport != NBODY_TRANSPORT_RCCL && cfg->transport != NBODY_TRANSPORT_PEER_COPY))
+        return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: unknown integrator, exchange or transport");
+    int64_t padded = 0, chunk = 0, split = 0;
+    if (nbody_multi_geometry(cfg->n_bodies, world, cfg->force_mode, cfg->split_len, &padded, &chunk, &split) != NBODY_OK)
+        return mfail(nullptr, NBODY_ERR_INVALID,
+                     "nbody_multi_create: bad geometry (n_bodies >= 0, split_len a multiple of 256, and the pair-once mode "
+                     "shards over 1, 2, 4 or 8 ranks)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return mfail(nullptr, NBODY_ERR_NO_DEVICE, std::string("nbody_multi_create: no HIP device (") + hipGetErrorString(e) +
+                                                       "); this library has no CPU path");
+    nbody_multi *m = new (std::nothrow) nbody_multi;
+    if (!m)
+        return mfail(nullptr, NBODY_ERR_ALLOC, "nbody_multi_create: host allocation failed");
+    m->cfg = *cfg;
+    m->world = world;
+    m->n_bodies = cfg->n_bodies;
+    m->n_padded = padded;
+    m->chunk = chunk;
+    m->split_len = split;
+    if (const char *t = getenv("NBODY_EXCHANGE_TIMEOUT_S"))
+        if (atof(t) > 0)
+            m->timeout_s = atof(t);
+    *made = m;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_destroy(nbody_multi *m);
+
+extern "C" int nbody_multi_create(nbody_multi **out, const nbody_multi_config *cfg, const int *devices, int n_devices)
+{
+    if (!devices || n_devices < 1)
+        return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: need at least one device");
+    nbody_multi *m = nullptr;
+    int rc = create_common(out, cfg, n_devices, &m);
+    if (rc != NBODY_OK)
+        return rc;
+    if (rccl(m))
+        for (int i = 0; i < n_devices; ++i)
+            for (int j = 0; j < i; ++j)
+                if (devices[i] == devices[j]) {
+                    delete m;
+                    return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: RCCL needs distinct devices (two ranks on one "
+                                                             "device: NBODY_TRANSPORT_PEER_COPY)");
+                }
+    m->ranks.resize((size_t)n_devices);
+    for (int i = 0; i < n_devices; ++i) {
+        m->ranks[(size_t)i].rank = i;
+        m->ranks[(size_t)i].device = devices[i];
+    }
+    rc = setup_ranks(m);
+    if (rc == NBODY_OK && rccl(m)) {
+        std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+        ncclResult_t r = ncclCommInitAll(comms.data(), n_devices, devices);
+        if (r != ncclSuccess)
+            rc = mfail(m, NBODY_ERR_DEVICE, std::string("ncclCommInitAll: RCCL: ") + ncclGetErrorString(r));
+        else
+            for (int i = 0; i < n_devices; ++i)
+                m->ranks[(size_t)i].nccl = comms[(size_t)i];
+    }
+    if (rc != NBODY_OK) {
+        g_multi_create_error = m->err;
+        nbody_multi_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_create_rank(nbody_multi **out, const nbody_multi_config *cfg, int device, int rank, int world_size,
+                                       const void *unique_id128)
+{
+    if (world_size < 1 || rank < 0 || rank >= world_size)
+        return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create_rank: rank outside [0, world_size)");
+    if (!unique_id128)
+        return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create_rank: unique id is NULL (nbody_multi_unique_id on rank 0, "
+                                                 "then hand the 128 bytes to every rank)");
+    nbody_multi *m = nullptr;
+    int rc = create_common(out, cfg, world_size, &m);
+    if (rc != NBODY_OK)
+        return rc;
+    if (!rccl(m) && world_size > 1) {
+        delete m;
+        return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create_rank: ranks in different processes exchange over RCCL only");
+    }
+    m->ranks.resize(1);
+    m->ranks[0].rank = rank;
+    m->ranks[0].device = device;
+    rc = setup_ranks(m);
+    if (rc == NBODY_OK && rccl(m)) {
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id128, sizeof id);
+        if (hipSetDevice(device) != hipSuccess)
+            rc = mfail(m, NBODY_ERR_DEVICE, "hipSetDevice failed");
+        else {
+            ncclResult_t r = ncclCommInitRank(&m->ranks[0].nccl, world_size, id, rank);
+            if (r != ncclSuccess)
+                rc = mfail(m, NBODY_ERR_DEVICE, std::string("ncclCommInitRank: RCCL: ") + ncclGetErrorString(r));
+        }
+    }
+    if (rc != NBODY_OK) {
+        g_multi_create_error = m->err;
+        nbody_multi_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_destroy(nbody_multi *m)
+{
+    if (!m)
+        return NBODY_OK;
+    for (Rank &r : m->ranks) {
+        (void)hipSetDevice(r.device);
+        for (hipStream_t s : {r.compute, r.side, r.comm})
+            if (s)
+                (void)hipStreamSynchronize(s);
+    }
+    for (size_t i = 0; i < m->ranks.size(); ++i) {
+        Rank &r = m->ranks[i];
+        (void)hipSetDevice(r.device);
+        if (r.nccl)
+            (void)ncclCommDestroy(r.nccl);
+        if (r.ctx)
+            nbody_destroy(r.ctx);
+        for (float *p : {r.pos, r.vel, r.colparts})
+            if (p)
+                (void)hipFree(p);
+        if (r.scratch)
+            (void)hipFree(r.scratch);
+        for (hipEvent_t e : {r.ev_start, r.ev_side})
+            if (e)
+                (void)hipEventDestroy(e);
+        for (hipEvent_t e : r.ev_hop)
+            if (e)
+                (void)hipEventDestroy(e);
+        for (Channel *c : {&m->ch_pos, &m->ch_col}) {
+            if (i < c->ready.size() && c->ready[i]) (void)hipEventDestroy(c->ready[i]);
+            if (i < c->done.size() && c->done[i]) (void)hipEventDestroy(c->done[i]);
+        }
+        for (hipStream_t s : {r.compute, r.side, r.comm})
+            if (s)
+                (void)hipStreamDestroy(s);
+    }
+    if (m->gather_vel) {
+        (void)hipSetDevice(m->ranks[0].device);
+        (void)hipFree(m->gather_vel);
+    }
+    delete m;
+    return NBODY_OK;
+}
+
+// ---- waiting, with failure detection ---------------------------------------------------------------------------------
+
+static int poll_async_errors(nbody_multi *m)
+{
+    for (Rank &r : m->ranks)
+        if (r.nccl) {
+            ncclResult_t async = ncclSuccess;
+            ncclResult_t q = ncclCommGetAsyncError(r.nccl, &async);
+            if (q != ncclSuccess || (async != ncclSuccess && async != ncclInProgress)) {
+                const ncclResult_t bad = q != ncclSuccess ? q : async;
+                return mfail(m, NBODY_ERR_DEVICE, "RCCL reported an asynchronous error on rank " + std::to_string(r.rank) + ": " +
+                                                      ncclGetErrorString(bad) + " (" + ncclGetLastError(r.nccl) + ")");
+            }
+        }
+    return NBODY_OK;
+}
+
+// Waits until every stream of every local rank has drained, polling RCCL for asynchronous errors; a wait longer than
+// the timeout aborts the communicators (a dead or stuck peer) and reports it instead of hanging.
+static int wait_all(nbody_multi *m)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        bool busy = false;
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            for (hipStream_t s : {r.compute, r.side, r.comm}) {
+                hipError_t e = hipStreamQuery(s);
+                if (e == hipErrorNotReady)
+                    busy = true;
+                else if (e != hipSuccess)
+                    return mfail(m, NBODY_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+            }
+        }
+        if (!busy)
+            break;
+        if ((++spins & 63u) == 0) {
+            int rc = poll_async_errors(m);
+            if (rc != NBODY_OK)
+                return rc;
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > m->timeout_s) {
+                for (Rank &r : m->ranks)
+                    if (r.nccl) {
+                        (void)ncclCommAbort(r.nccl);
+                        r.nccl = nullptr;
+                    }
+                return mfail(m, NBODY_ERR_DEVICE, "timed out after " + std::to_string((int)waited) +
+                                                      " s waiting for the step (a peer rank is gone or stuck); the RCCL "
+                                                      "communicators were aborted");
+            }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 20 : 200));
+    }
+    for (Rank &r : m->ranks) {
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipGetLastError());
+    }
+    return poll_async_errors(m);
+}
+
+extern "C" int nbody_multi_sync(nbody_multi *m)
+{
+    if (!m)
+        return NBODY_ERR_INVALID;
+    return wait_all(m);
+}
+
+extern "C" int nbody_multi_set_timeout(nbody_multi *m, double seconds)
+{
+    if (!m || !(seconds > 0))
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_timeout: seconds must be > 0");
+    m->timeout_s = seconds;
+    return NBODY_OK;
+}
+
+// ---- the exchanges -------------------------------------------------------------------------------------------------
+
+typedef float *Rank::*RankBuffer;
+
+// All-gather of equal slices, in place: rank q's slice is [q * slice_floats, (q + 1) * slice_floats) of every rank's
+// buffer.  Enqueued on the comm streams behind each rank's `ready` point on its compute stream.
+static int start_allgather(nbody_multi *m, Channel &ch, RankBuffer buf, size_t slice_floats)
+{
+    const size_t nl = m->ranks.size();
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(ch.ready[i], r.compute));
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        if (rccl(m)) {  // the collective itself orders the ranks: nobody's slice is written before everybody has entered
+            MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[i], 0));
+        } else {        // peer copies write into the others' buffers: wait until they have stopped reading them
+            for (size_t j = 0; j < nl; ++j)
+                MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[j], 0));
+        }
+    }
+    if (rccl(m)) {
+        MNCCL(m, ncclGroupStart());
+        for (Rank &r : m->ranks) {
+            float *b = r.*buf;
+            ncclResult_t q = ncclAllGather(b + (size_t)r.rank * slice_floats, b, slice_floats, ncclFloat, r.nccl, r.comm);
+            if (q != ncclSuccess) {
+                (void)ncclGroupEnd();
+                return mfail(m, NBODY_ERR_DEVICE, std::string("ncclAllGather: RCCL: ") + ncclGetErrorString(q));
+            }
+        }
+        MNCCL(m, ncclGroupEnd());
+    } else {
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            for (Rank &d : m->ranks)
+                if (d.rank != r.rank)
+                    MHIP(m, hipMemcpyPeerAsync(d.*buf + (size_t)r.rank * slice_floats, d.device,
+                                               r.*buf + (size_t)r.rank * slice_floats, r.device, slice_floats * sizeof(float),
+                                               r.comm));
+        }
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(ch.done[i], r.comm));
+    }
+    return NBODY_OK;
+}
+
+// Orders `stream` of local rank i behind the arrival of every other rank's slice.
+static int wait_allgather(nbody_multi *m, Channel &ch, size_t i, hipStream_t stream)
+{
+    Rank &r = m->ranks[i];
+    MHIP(m, hipSetDevice(r.device));
+    if (rccl(m)) {
+        MHIP(m, hipStreamWaitEvent(stream, ch.done[i], 0));
+    } else {
+        for (size_t j = 0; j < m->ranks.size(); ++j)
+            if (j != i)
+                MHIP(m, hipStreamWaitEvent(stream, ch.done[j], 0));
+    }
+    return NBODY_OK;
+}
+
+// The position ring: P - 1 hops on the comm streams; ev_hop[h] of a rank marks the arrival of hop h at that rank (RCCL)
+// or the departure of its hop-h copy towards rank + 1 (peer copies).
+static int start_ring(nbody_multi *m)
+{
+    const size_t nl = m->ranks.size();
+    const int P = m->world;
+    const size_t chunk_floats = 4 * (size_t)m->chunk;
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(m->ch_pos.ready[i], r.compute));
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        if (rccl(m)) {
+            MHIP(m, hipStreamWaitEvent(r.comm, m->ch_pos.ready[i], 0));
+        } else {
+            for (size_t j = 0; j < nl; ++j)
+                MHIP(m, hipStreamWaitEvent(r.comm, m->ch_pos.ready[j], 0));
+        }
+    }
+    for (int h = 1; h < P; ++h) {
+        if (rccl(m)) {
+            MNCCL(m, ncclGroupStart());
+            for (Rank &r : m->ranks) {
+                int send_c = 0, recv_c = 0;
+                nbody_multi_ring_schedule(r.rank, P, h, &send_c, &recv_c);
+                ncclResult_t q = ncclSend(r.pos + (size_t)send_c * chunk_floats, chunk_floats, ncclFloat, (r.rank + 1) % P, r.nccl,
+                                          r.comm);
+                if (q == ncclSuccess)
+                    q = ncclRecv(r.pos + (size_t)recv_c * chunk_floats, chunk_floats, ncclFloat, (r.rank + P - 1) % P, r.nccl,
+                                 r.comm);
+                if (q != ncclSuccess) {
+                    (void)ncclGroupEnd();
+                    return mfail(m, NBODY_ERR_DEVICE, std::string("ncclSend/ncclRecv: RCCL: ") + ncclGetErrorString(q));
+                }
+            }
+            MNCCL(m, ncclGroupEnd());
+        } else {
+            for (size_t i = 0; i < nl; ++i) {
+                Rank &r = m->ranks[i];
+                Rank &next = m->ranks[(i + 1) % nl];  // all ranks are local here, in rank order
+                Rank &prev = m->ranks[(i + nl - 1) % nl];
+                int send_c = 0;
+                nbody_multi_ring_schedule(r.rank, P, h, &send_c, nullptr);
+                MHIP(m, hipSetDevice(r.device));
+                if (h > 1)  // the chunk passed on arrived with the previous hop, on the previous rank's stream
+                    MHIP(m, hipStreamWaitEvent(r.comm, prev.ev_hop[(size_t)h - 1], 0));
+                MHIP(m, hipMemcpyPeerAsync(next.pos + (size_t)send_c * chunk_floats, next.device,
+                                           r.pos + (size_t)send_c * chunk_floats, r.device, chunk_floats * sizeof(float), r.comm));
+            }
+        }
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            MHIP(m, hipEventRecord(r.ev_hop[(size_t)h], r.comm));
+        }
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(m->ch_pos.done[i], r.comm));
+    }
+    return NBODY_OK;
+}
+
+static int wait_ring_hop(nbody_multi *m, size_t i, int h, hipStream_t stream)
+{
+    Rank &r = m->ranks[i];
+    const size_t nl = m->ranks.size();
+    MHIP(m, hipSetDevice(r.device));
+    hipEvent_t e = rccl(m) ? r.ev_hop[(size_t)h] : m->ranks[(i + nl - 1) % nl].ev_hop[(size_t)h];
+    MHIP(m, hipStreamWaitEvent(stream, e, 0));
+    return NBODY_OK;
+}
+
+static int exchange_own_rows(nbody_multi *m)
+{
+    if (m->world == 1)
+        return NBODY_OK;
+    int rc = m->cfg.exchange == NBODY_EXCHANGE_RING ? start_ring(m) : start_allgather(m, m->ch_pos, &Rank::pos, 4 * (size_t)m->chunk);
+    if (rc == NBODY_OK)
+        m->exchange_in_flight = true;
+    return rc;
+}
+
+// ---- the step --------------------------------------------------------------------------------------------------------
+
+// Partial sums of every local rank's rows from every column: the own chunk first (it needs no remote data and runs
+// beside the exchange in flight), the other chunks as they become current.
+static int forces_all_columns(nbody_multi *m, float softening)
+{
+    const size_t nl = m->ranks.size();
+    const int P = m->world;
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        const int64_t lo = (int64_t)r.rank * m->chunk;
+        MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+        if (P > 1) {
+            MHIP(m, hipSetDevice(r.device));
+            MHIP(m, hipEventRecord(r.ev_start, r.compute));  // the previous update (the reader of the partial sums) is done
+        }
+        MCTX(m, r, nbody_forces(r.ctx, r.pos, lo, m->chunk, softening));
+    }
+    if (P == 1)
+        return NBODY_OK;
+    if (m->cfg.exchange == NBODY_EXCHANGE_RING && m->exchange_in_flight) {
+        for (int h = 1; h < P; ++h)
+            for (size_t i = 0; i < nl; ++i) {
+                Rank &r = m->ranks[i];
+                int recv_c = 0;
+                nbody_multi_ring_schedule(r.rank, P, h, nullptr, &recv_c);
+                int rc = wait_ring_hop(m, i, h, r.compute);
+                if (rc != NBODY_OK)
+                    return rc;
+                MCTX(m, r, nbody_forces(r.ctx, r.pos, (int64_t)recv_c * m->chunk, m->chunk, softening));
+            }
+        m->exchange_in_flight = false;
+        return NBODY_OK;
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        const int64_t lo = (int64_t)r.rank * m->chunk;
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipStreamWaitEvent(r.side, r.ev_start, 0));
+        if (m->exchange_in_flight) {
+            int rc = wait_allgather(m, m->ch_pos, i, r.side);
+            if (rc != NBODY_OK)
+                return rc;
+        }
+        // all other chunks in one launch on the second stream: its workgroups fill the CUs the first launch's tail leaves idle
+        MCTX(m, r, nbody_set_stream(r.ctx, r.side));
+        MCTX(m, r, nbody_forces_complement(r.ctx, r.pos, lo, m->chunk, softening));
+        MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(r.ev_side, r.side));
+        MHIP(m, hipStreamWaitEvent(r.compute, r.ev_side, 0));
+    }
+    m->exchange_in_flight = false;
+    return NBODY_OK;
+}
+
+// Pair-once mode: the column-side sums of every rank's groups, for every body, gathered from every rank.
+static int sum_forces(nbody_multi *m)
+{
+    if (!pair_once(m) || m->world == 1)
+        return NBODY_OK;  // one context: nbody_update / nbody_kdk_* run the reduction themselves
+    for (Rank &r : m->ranks)
+        MCTX(m, r, nbody_sym_reduce(r.ctx));
+    const size_t slice = 4 * (size_t)(NBODY_SYM_GROUPS / m->world) * (size_t)m->n_padded;
+    int rc = start_allgather(m, m->ch_col, &Rank::colparts, slice);
+    for (size_t i = 0; rc == NBODY_OK && i < m->ranks.size(); ++i)
+        rc = wait_allgather(m, m->ch_col, i, m->ranks[i].compute);
+    return rc;
+}
+
+static int step_async(nbody_multi *m, float dt, float softening)
+{
+    if (!m->have_state && m->n_padded)
+        return mfail(m, NBODY_ERR_STATE, "nbody_multi_step: call nbody_multi_set_state first");
+    int rc;
+    if (m->cfg.integrator == NBODY_INTEGRATOR_KDK) {
+        // velocity Verlet: the drifted rows are exchanged BEFORE the forces; the own-chunk launch still runs beside the exchange
+        if (!m->kdk_ready) {
+            rc = forces_all_columns(m, softening);
+            if (rc == NBODY_OK)
+                rc = sum_forces(m);
+            if (rc != NBODY_OK)
+                return rc;
+            for (Rank &r : m->ranks)
+                MCTX(m, r, nbody_kdk_prepare(r.ctx));
+            m->kdk_ready = true;
+        }
+        for (Rank &r : m->ranks)
+            MCTX(m, r, nbody_kdk_kick_drift(r.ctx, r.pos, r.vel, dt));
+        rc = exchange_own_rows(m);
+        if (rc == NBODY_OK)
+            rc = forces_all_columns(m, softening);
+        if (rc == NBODY_OK)
+            rc = sum_forces(m);
+        if (rc != NBODY_OK)
+            return rc;
+        for (Rank &r : m->ranks)
+            MCTX(m, r, nbody_kdk_kick(r.ctx, r.vel, dt));
+        return poll_async_errors(m);
+    }
+    rc = forces_all_columns(m, softening);
+    if (rc == NBODY_OK)
+        rc = sum_forces(m);
+    if (rc != NBODY_OK)
+        return rc;
+    for (Rank &r : m->ranks)
+        MCTX(m, r, nbody_update(r.ctx, r.pos, r.vel, dt));
+    rc = exchange_own_rows(m);
+    return rc == NBODY_OK ? poll_async_errors(m) : rc;
+}
+
+// Replica current on every rank: an exchange still in flight is simply waited for (its data are not consumed twice).
+static int settle(nbody_multi *m)
+{
+    int rc = wait_all(m);
+    m->exchange_in_flight = false;  // everything has landed: the next force launches need not wait for anything
+    return rc;
+}
+
+extern "C" int nbody_multi_step_async(nbody_multi *m, float dt, float softening)
+{
+    if (!m)
+        return NBODY_ERR_INVALID;
+    return step_async(m, dt, softening);
+}
+
+extern "C" int nbody_multi_step(nbody_multi *m, float dt, float softening)
+{
+    if (!m)
+        return NBODY_ERR_INVALID;
+    int rc = step_async(m, dt, softening);
+    return rc == NBODY_OK ? settle(m) : rc;
+}
+
+extern "C" int nbody_multi_step_n(nbody_multi *m, int k, float dt, float softening)
+{
+    if (!m || k < 0)
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_step_n: bad argument");
+    for (int s = 0; s < k; ++s) {
+        int rc = step_async(m, dt, softening);
+        if (rc != NBODY_OK)
+            return rc;
+    }
+    return settle(m);
+}
+
+// ---- state in and out ------------------------------------------------------------------------------------------------
+
+extern "C" int nbody_multi_set_state(nbody_multi *m, const float *host_pos, const float *host_vel)
+{
+    if (!m || ((!host_pos || !host_vel) && m->n_bodies))
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_state: NULL argument");
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    // padding = zero-mass bodies at the origin, the reference's own device (kernel.cu:265-277): they add exactly 0
+    std::vector<float> pos(4 * (size_t)m->n_padded, 0.f), vel(4 * (size_t)m->n_padded, 0.f);
+    if (m->n_bodies) {
+        std::memcpy(pos.data(), host_pos, sizeof(float) * 4 * (size_t)m->n_bodies);
+        std::memcpy(vel.data(), host_vel, sizeof(float) * 4 * (size_t)m->n_bodies);
+    }
+    for (Rank &r : m->ranks) {
+        if (!m->n_padded)
+            break;
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipMemcpyAsync(r.pos, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice, r.compute));
+        MHIP(m, hipMemcpyAsync(r.vel, vel.data() + 4 * (size_t)r.rank * (size_t)m->chunk, sizeof(float) * 4 * (size_t)m->chunk,
+                               hipMemcpyHostToDevice, r.compute));
+        MHIP(m, hipStreamSynchronize(r.compute));
+        MCTX(m, r, nbody_invalidate_forces(r.ctx));
+    }
+    m->kdk_ready = false;
+    m->have_state = true;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_set_particle_softening(nbody_multi *m, const float *host_eps)
+{
+    if (!m)
+        return NBODY_ERR_INVALID;
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    std::vector<float> eps;
+    if (host_eps) {
+        eps.assign((size_t)m->n_padded, 0.f);
+        std::memcpy(eps.data(), host_eps, sizeof(float) * (size_t)m->n_bodies);
+    }
+    for (Rank &r : m->ranks)
+        MCTX(m, r, nbody_upload_particle_softening(r.ctx, host_eps ? eps.data() : nullptr));
+    m->kdk_ready = false;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_download(nbody_multi *m, float *host_pos, float *host_vel)
+{
+    if (!m)
+        return NBODY_ERR_INVALID;
+    if (!m->have_state && m->n_padded)
+        return mfail(m, NBODY_ERR_STATE, "nbody_multi_download: no state was ever set");
+    int rc = settle(m);
+    if (rc != NBODY_OK || !m->n_bodies)
+        return rc;
+    Rank &r0 = m->ranks[0];
+    MHIP(m, hipSetDevice(r0.device));
+    if (host_pos)
+        MHIP(m, hipMemcpy(host_pos, r0.pos, sizeof(float) * 4 * (size_t)m->n_bodies, hipMemcpyDeviceToHost));
+    if (!host_vel)
+        return NBODY_OK;
+    const size_t chunk_floats = 4 * (size_t)m->chunk;
+    auto copy_rows = [&](const float *dev_rows, int rank) -> hipError_t {  // the real bodies among this rank's rows
+        const int64_t lo = (int64_t)rank * m->chunk, hi = std::min(lo + m->chunk, m->n_bodies);
+        if (hi <= lo)
+            return hipSuccess;
+        return hipMemcpy(host_vel + 4 * (size_t)lo, dev_rows, sizeof(float) * 4 * (size_t)(hi - lo), hipMemcpyDeviceToHost);
+    };
+    if (all_local(m)) {
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            MHIP(m, copy_rows(r.vel, r.rank));
+        }
+        return NBODY_OK;
+    }
+    if (!m->gather_vel)
+        MHIP(m, hipMalloc((void **)&m->gather_vel, sizeof(float) * 4 * (size_t)m->n_padded));
+    MNCCL(m, ncclAllGather(r0.vel, m->gather_vel, chunk_floats, ncclFloat, r0.nccl, r0.comm));
+    rc = wait_all(m);
+    if (rc != NBODY_OK)
+        return rc;
+    MHIP(m, hipMemcpy(host_vel, m->gather_vel, sizeof(float) * 4 * (size_t)m->n_bodies, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+// Sums `n` doubles over all ranks (in rank order inside this process; ncclSum across processes).
+static int allreduce_sum(nbody_multi *m, double *v, int n)
+{
+    if (all_local(m) || m->world == 1)
+        return NBODY_OK;
+    Rank &r = m->ranks[0];
+    MHIP(m, hipSetDevice(r.device));
+    MHIP(m, hipMemcpyAsync(r.scratch, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, r.comm));
+    MNCCL(m, ncclAllReduce(r.scratch, r.scratch, (size_t)n, ncclDouble, ncclSum, r.nccl, r.comm));
+    MHIP(m, hipMemcpyAsync(v, r.scratch, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, r.comm));
+    return wait_all(m);
+}
+
+extern "C" int nbody_multi_energy(nbody_multi *m, float softening, double *out3)
+{
+    if (!m || !out3)
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_energy: NULL argument");
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    double sum[4] = {0, 0, 0, 0};
+    for (Rank &r : m->ranks) {
+        double e[3];
+        MCTX(m, r, nbody_energy(r.ctx, r.pos, r.vel, softening, e));
+        for (int k = 0; k < 3; ++k)
+            sum[k] += e[k];
+    }
+    rc = allreduce_sum(m, sum, 4);
+    for (int k = 0; k < 3; ++k)
+        out3[k] = sum[k];
+    return rc;
+}
+
+extern "C" int nbody_multi_momentum(nbody_multi *m, double *out4)
+{
+    if (!m || !out4)
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_momentum: NULL argument");
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    double sum[4] = {0, 0, 0, 0};
+    for (Rank &r : m->ranks) {
+        double p[4];
+        MCTX(m, r, nbody_momentum(r.ctx, r.pos, r.vel, p));
+        for (int k = 0; k < 4; ++k)
+            sum[k] += p[k];
+    }
+    rc = allreduce_sum(m, sum, 4);
+    for (int k = 0; k < 4; ++k)
+        out4[k] = sum[k];
+    return rc;
+}
+
+// out2 = {smallest, largest} checksum of the position replicas over ALL ranks: equal when every rank holds the same bits.
+extern "C" int nbody_multi_replica_checksums(nbody_multi *m, uint64_t *out2)
+{
+    if (!m || !out2)
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_replica_checksums: NULL argument");
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (Rank &r : m->ranks) {
+        unsigned long long s = 0;
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipMemsetAsync(r.scratch, 0, sizeof(unsigned long long), r.compute));
+        if (m->n_padded)
+            hipLaunchKernelGGL(nbody_checksum_kernel, dim3(1024), dim3(256), 0, r.compute, reinterpret_cast<const unsigned *>(r.pos),
+                               4 * (size_t)m->n_padded, r.scratch);
+        MHIP(m, hipGetLastError());
+        MHIP(m, hipMemcpyAsync(&s, r.scratch, sizeof s, hipMemcpyDeviceToHost, r.compute));
+        MHIP(m, hipStreamSynchronize(r.compute));
+        lo = std::min(lo, s);
+        hi = std::max(hi, s);
+    }
+    if (!all_local(m) && m->world > 1) {
+        Rank &r = m->ranks[0];
+        unsigned long long v[2] = {hi, ~lo};  // max over ranks of {s, ~s} = {max s, ~min s}
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipMemcpyAsync(r.scratch, v, sizeof v, hipMemcpyHostToDevice, r.comm));
+        MNCCL(m, ncclAllReduce(r.scratch, r.scratch, 2, ncclUint64, ncclMax, r.nccl, r.comm));
+        MHIP(m, hipMemcpyAsync(v, r.scratch, sizeof v, hipMemcpyDeviceToHost, r.comm));
+        rc = wait_all(m);
+        if (rc != NBODY_OK)
+            return rc;
+        hi = v[0];
+        lo = ~v[1];
+    }
+    out2[0] = lo;
+    out2[1] = hi;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_info(const nbody_multi *m, int64_t *out8)
+{
+    if (!m || !out8)
+        return NBODY_ERR_INVALID;
+    int nccl_ranks = 0;
+    for (const Rank &r : m->ranks)
+        if (r.nccl) {
+            int c = 0;
+            if (ncclCommCount(r.nccl, &c) == ncclSuccess)
+                nccl_ranks = c;
+        }
+    out8[0] = m->n_bodies;
+    out8[1] = m->n_padded;
+    out8[2] = m->chunk;
+    out8[3] = m->split_len;
+    out8[4] = m->world;
+    out8[5] = (int64_t)m->ranks.size();
+    out8[6] = nccl_ranks;  // ranks of the RCCL communicator (0: peer copies / a single rank without RCCL)
+    out8[7] = m->cfg.exchange;
+    return NBODY_OK;
+}
+
+extern "C" nbody_ctx *nbody_multi_shard(nbody_multi *m, int local_index)
+{
+    return (m && local_index >= 0 && local_index < (int)m->ranks.size()) ? m->ranks[(size_t)local_index].ctx : nullptr;
+}
+
+extern "C" float *nbody_multi_positions_device(nbody_multi *m, int local_index)
+{
+    return (m && local_index >= 0 && local_index < (int)m->ranks.size()) ? m->ranks[(size_t)local_index].pos : nullptr;
+}
+
+extern "C" float *nbody_multi_velocities_device(nbody_multi *m, int local_index)
+{
+    return (m && local_index >= 0 && local_index < (int)m->ranks.size()) ? m->ranks[(size_t)local_index].vel : nullptr;
+}

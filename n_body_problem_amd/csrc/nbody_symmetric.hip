@@ -29,6 +29,10 @@
 // operations per 64 x 4 pairs) against 2 x (12 + 1) for the two ordered interactions it replaces.
 #include "nbody_kernels.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace nbody {
 
 // A tile's workgroup has W wave64 (W x 256 rows per pass): 4 for splits of 1024 bodies or more, fewer for the shorter
@@ -56,7 +60,7 @@ __device__ __forceinline__ float wave_rol1(float v) { return dpp_move<0x134>(v);
 //   shared            inv^2 = v44/v48 (bank 0)   inv^3 = v46/v50 (bank 2)   s_col = v47/v51 (bank 3)
 //   row sums k        az = v(52+4k) (bank 0)  ax = v(53+4k) (bank 1)  ay = v(54+4k) (bank 2)
 //   column sums       cx = v45 (bank 1)  cy = v68 (bank 0)  cz = v49 (bank 1)   (travelling)
-//   v11 = eps^2 (bank 3)   v69 = 1e-24 (GUARD, bank 1)   v59 = 4 * ((lane + 1) mod 64), the permute's source lane
+//   v11 = eps^2 (bank 3)   v69 = FLT_MIN, v70 = +inf (GUARD)   v59 = 4 * ((lane + 1) mod 64), the permute's source lane
 //   v0 = LDS byte address of the next read = v10 | (v1 & v55): v1 counts 16 bytes per step from 16*lane, v55 = 1023,
 //   v10 = the wave's 1 KiB-aligned group buffer -- column (lane + s) mod 64 without a second copy of the group.
 typedef float nb_f4 __attribute__((ext_vector_type(4)));
@@ -64,7 +68,7 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     "v_sub_f32_e32 " D0 ", " PX ", " X "\n\tv_sub_f32_e32 " D1 ", " PY ", " Y "\n\tv_sub_f32_e32 " D2 ", " PZ ", " Z "\n\t" \
     "v_fma_f32 " R ", " D0 ", " D0 ", v11\n\tv_fmac_f32_e32 " R ", " D1 ", " D1 "\n\tv_fmac_f32_e32 " R ", " D2 ", " D2 "\n\t" GRD(R)
 #define SY_NOGUARD(R) ""
-#define SY_GUARD(R) "v_max_f32_e32 " R ", v69, " R "\n\t"
+#define SY_GUARD(R) "v_cmp_le_f32_e32 vcc, v69, " R "\n\tv_cndmask_b32_e32 " R ", v70, " R ", vcc\n\t"
 #define SY_POST(PM, M, AX, AY, AZ, D0, D1, D2, R, Q, T, SC)                                                      \
     "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " T ", " R ", " Q "\n\t"                                      \
     "v_mul_f32_e32 " SC ", " M ", " T "\n\tv_mul_f32_e32 " R ", " PM ", " T "\n\t"                                    \
@@ -216,16 +220,16 @@ __global__ __launch_bounds__(64 * W) void force_sym_kernel(SymArgs a)
                 unsigned off = 16u * (unsigned)lane, addr = 0, cnt;
                 const unsigned base = (unsigned)(size_t)lds.stage, mask = 1023u, next_lane = 4u * ((lane + 1) & 63);
                 float eps2 = a.eps2;  // in a VGPR: an SGPR source operand costs an fp32 instruction two extra cycles
-                const float tiny = 1.0e-24f;
+                const float tiny = kGuardMin, pinf = __builtin_inff();
 #define SY_OPERANDS                                                                                                   \
                 : "+{v53}"(ax[0]), "+{v54}"(ay[0]), "+{v52}"(az[0]), "+{v57}"(ax[1]), "+{v58}"(ay[1]), "+{v56}"(az[1]),      \
                   "+{v61}"(ax[2]), "+{v62}"(ay[2]), "+{v60}"(az[2]), "+{v65}"(ax[3]), "+{v66}"(ay[3]), "+{v64}"(az[3]),      \
                   "+{v45}"(cx), "+{v68}"(cy), "+{v49}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)                  \
                 : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]), "{v11}"(eps2),     \
-                  "{v69}"(tiny), "{v10}"(base), "{v55}"(mask), "{v59}"(next_lane)                                                              \
+                  "{v69}"(tiny), "{v70}"(pinf), "{v10}"(base), "{v55}"(mask), "{v59}"(next_lane)                                                              \
                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",      \
                   "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v50", "v51", "scc",    \
-                  "memory"
+                  "vcc", "memory"
                 if (GUARD)
                     asm volatile(SY_GROUP_LOOP(SY_GUARD) SY_OPERANDS);
                 else
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
                     r2 = __builtin_fmaf(dy, dy, r2);
                     r2 = __builtin_fmaf(dz, dz, r2);
                     if (GUARD)
-                        r2 = __builtin_fmaxf(r2, 1.0e-24f);
+                        r2 = guard_r2(r2);
                     const float inv = __builtin_amdgcn_rsqf(r2);
                     float inv3 = inv * (inv * inv);
                     if (DIAG)
@@ -376,8 +380,9 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
     // DIAG: both sides of the split, P_row[0][b]; else the column sums, P_col[R][d-1][.]
     float4 *out = DIAG ? a.row_partials + (rowbase - a.row_lo)
                        : sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);
+    const int col_hi = DIAG ? row_hi : a.n_total;  // a diagonal tile's columns are the context's own rows
     for (int c = tid; c < L; c += kSymThreads)
-        if (colbase + c < a.n_total)
+        if (colbase + c < col_hi)
             out[c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
 }
 
@@ -396,10 +401,24 @@ static hipError_t sym_launch(K kernel, int blocks, int waves, size_t lds, const 
 {
     if (blocks <= 0)
         return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    // the attribute is per function and device: set it once (and again only if a longer split needs more)
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess)
         return e;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        size_t &have = granted[{reinterpret_cast<const void *>(kernel), dev}];
+        if (have < lds) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds);
+            if (e != hipSuccess)
+                return e;
+            have = lds;
+        }
+    }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }

@@ -1,22 +1,21 @@
-"""Rows sharded over the GPUs of one node: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
+"""Rows sharded over several ranks with the exchange carried by ``torch.distributed`` -- the REHEARSAL harness.
 
-The reference is single-GPU (nothing to mirror); the path shards naturally because the
-rows of the interaction matrix are independent given all positions:
+The product's multi-GPU step lives behind the C ABI (``nbody_multi_*``, csrc/nbody_multi.hip, Python view
+:class:`n_body_problem_amd.multi.MultiGpuSystem`): RCCL all-gather / ring inside the library, one process per GPU or
+all GPUs in one process.  :func:`sharded_system` returns that object whenever the process group's backend is ``nccl``
+(= RCCL) or there is no process group.
 
-* rank r integrates the contiguous rows ``[r*C, (r+1)*C)`` (its velocities, its partial sums) and holds a
-  full-size replica of the position buffer (16 MiB at N = 2^20);
-* per step ONE exchange, the all-gather of the updated position slices (C x 16 B per rank), overlapped
-  with the force kernel on the rank's OWN column chunk, which needs no remote data; only then does the
-  compute stream wait for remote chunks.
+What stays here is the same step spelled out in Python over ``torch.distributed`` with a host-staged backend (gloo),
+for the two situations RCCL cannot serve: several ranks sharing ONE GPU (RCCL refuses duplicate devices) and ranks
+without any GPU, where ``kernels_factory`` injects a CPU stand-in for the kernels (tests/_sharded_worker.py) so that
+the sharding, the pair-once row/column/group data flow and both exchange schedules are checked under ``gloo`` with
+world sizes 2 and 4.  Same geometry, same call order per rank, same bits as the library path:
 
-``exchange="allgather"``: one RCCL all-gather per step (RCCL runs it as a ring over xGMI), issued right after
-the update kernel; the next step's own-chunk force kernel runs beside it.
-``exchange="ring"``: the ring spelled out as P-1 send/recv hops on a communication stream; the force
-kernel of chunk (r-h) starts as soon as hop h has landed, while later hops are still on the wire.
-
-Determinism: chunk boundaries are multiples of ``split_len`` (a function of the body count only), every
-split's partial sum is one ascending FMA chain and the splits are added in ascending order, so the state
-is bit-identical to the single-GPU run for any world size, exchange mode and chunk arrival order.
+* rank r integrates the contiguous rows ``[r*C, (r+1)*C)`` and holds a full replica of the positions;
+* per step ONE exchange of the updated position slices, overlapped with the force kernel on the rank's OWN column
+  chunk; ``exchange="ring"`` spells it out as P-1 send/recv hops, the force kernel of chunk (r-h) starting as hop h lands;
+* chunk boundaries are multiples of ``split_len`` (whole split groups in the pair-once mode), every partial sum has one
+  writer and a fixed order, so the state is bit-identical to the single-GPU run for any world size and exchange.
 """
 from __future__ import annotations
 
@@ -120,15 +119,9 @@ class ShardedNBodySystem:
         self.velocities = self.kernels.velocities    # own rows, (chunk, 4)
         self._on_gpu = bool(self.positions.is_cuda)
         backend = dist.get_backend(group) if self.distributed else "none"
-        self._rccl = self._on_gpu and backend == "nccl"
-        # The all-gather sends a staged copy of the own chunk (2 MiB at N = 2^20, P = 8: one ~3 us copy per step)
-        # and receives into the replica; RCCL then rewrites the own chunk with the bytes it already holds while the
-        # next step's own-chunk kernel may be reading them, which is harmless.  NBODY_ALLGATHER_INPLACE=1 gathers
-        # in place instead (sendbuff == recvbuff + rank*count, no self copy).
-        import os
-        self._inplace = self._rccl and os.environ.get("NBODY_ALLGATHER_INPLACE", "0") == "1"
-        self._send = None if self._inplace else torch.empty_like(self.positions[:self.chunk])
-        self._comm_stream = torch.cuda.Stream(device=self.positions.device) if self._on_gpu else None
+        if backend == "nccl" and kernels_factory is None:
+            raise ValueError("the RCCL exchange lives in the library: use sharded_system() / MultiGpuSystem.from_torch_distributed()")
+        self._send = torch.empty_like(self.positions[:self.chunk])
         self._side_stream = torch.cuda.Stream(device=self.positions.device) if self._on_gpu else None
         self._pending = None   # allgather mode: work handle of the exchange in flight
         self._stale = False    # ring mode: remote chunks of the replica are one update behind
@@ -191,36 +184,19 @@ class ShardedNBodySystem:
             self._pending = None
 
     def _start_allgather(self) -> None:
-        dist = self._dist
-        if self._inplace:
-            send = self._chunk(self.rank)
-        else:
-            self._send.copy_(self._chunk(self.rank))
-            send = self._send
-        self._pending = dist.all_gather_into_tensor(self.positions, send, group=self.group, async_op=True)
+        self._send.copy_(self._chunk(self.rank))
+        self._pending = self._dist.all_gather_into_tensor(self.positions, self._send, group=self.group, async_op=True)
 
     def _peer(self, r: int) -> int:
         r %= self.world_size
         return self._dist.get_global_rank(self.group, r) if self.group is not None else r
 
     def _ring_hop(self, send_c: int, recv_c: int) -> None:
-        """One hop: chunk send_c goes to rank+1 while chunk recv_c arrives from rank-1, in place in the replica.
-        On return the CURRENT stream is ordered after the arrival; the hop itself runs on the comm stream."""
+        """One hop: chunk send_c goes to rank+1 while chunk recv_c arrives from rank-1, in place in the replica (blocking,
+        staged through host memory when the replica is on a GPU)."""
         torch, dist = self._torch, self._dist
         nxt, prv = self._peer(self.rank + 1), self._peer(self.rank - 1)
-        if self._rccl:  # RCCL: device buffers, ordered on the communication stream
-            ops = [dist.P2POp(dist.isend, self._chunk(send_c), nxt, group=self.group),
-                   dist.P2POp(dist.irecv, self._chunk(recv_c), prv, group=self.group)]
-            with torch.cuda.stream(self._comm_stream):
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()  # orders the comm stream (not the host) after the transfer
-                landed = torch.cuda.Event()
-                landed.record(self._comm_stream)
-            torch.cuda.current_stream(self.positions.device).wait_event(landed)
-            return
-        # any other backend (gloo in the tests): blocking, staged through host memory when the replica is on a GPU
         if self._on_gpu:
-            self._comm_stream.synchronize()
             torch.cuda.current_stream(self.positions.device).synchronize()
         send = self._chunk(send_c).cpu() if self._on_gpu else self._chunk(send_c)
         recv = torch.empty_like(send) if self._on_gpu else self._chunk(recv_c)
@@ -234,8 +210,6 @@ class ShardedNBodySystem:
         """Bring every chunk of the replica up to date without computing anything."""
         self._drain()
         if self._stale:
-            if self._on_gpu:
-                self._comm_stream.wait_stream(self._torch.cuda.current_stream(self.positions.device))
             for _, send_c, recv_c in ring_schedule(self.rank, self.world_size):
                 self._ring_hop(send_c, recv_c)
             self._stale = False
@@ -247,8 +221,6 @@ class ShardedNBodySystem:
         k = self.kernels
         lo = self.row_lo
         if self._stale:  # ring mode, remote chunks outstanding
-            if self._on_gpu:  # hops may start once the kernel that wrote the own rows (already enqueued) is done
-                self._comm_stream.wait_stream(self._torch.cuda.current_stream(self.positions.device))
             k.forces(lo, self.chunk, softening)              # own chunk: runs beside the first hops
             for _, send_c, recv_c in ring_schedule(self.rank, self.world_size):
                 self._ring_hop(send_c, recv_c)
@@ -347,3 +319,17 @@ class ShardedNBodySystem:
         self._refresh()
         if hasattr(self.kernels, "close"):
             self.kernels.close()
+
+
+def sharded_system(num_bodies: int, device: int = 0, group=None, exchange: str = "allgather", force_mode: str = "one_sided",
+                   integrator: str = "kick_drift", split_len: int = 0):
+    """The sharded system of this process's rank: the library-owned RCCL exchange (``MultiGpuSystem``) when the process
+    group's backend is ``nccl`` or there is no process group, the host-staged rehearsal harness otherwise (gloo)."""
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
+    if not distributed or dist.get_backend(group) == "nccl":
+        from .multi import MultiGpuSystem
+        return MultiGpuSystem.from_torch_distributed(num_bodies, device, group=group, exchange=exchange, force_mode=force_mode,
+                                                     integrator=integrator, split_len=split_len)
+    return ShardedNBodySystem(num_bodies, group=group, device=device, exchange=exchange, force_mode=force_mode,
+                              integrator=integrator, split_len=split_len)

@@ -213,13 +213,12 @@ class NBodySystem:
         check(self._lib.nbody_timing_enable(self._ctx, 1 if on else 0), self._ctx)
 
     def read_timing(self) -> dict:
-        """HIP-event totals since the last read: force/update milliseconds and launch counts."""
-        f_ms, u_ms = ctypes.c_double(0), ctypes.c_double(0)
-        f_n, u_n = ctypes.c_int64(0), ctypes.c_int64(0)
-        check(self._lib.nbody_timing_read(self._ctx, ctypes.byref(f_ms), ctypes.byref(f_n), ctypes.byref(u_ms),
-                                          ctypes.byref(u_n)), self._ctx)
-        return {"force_ms": f_ms.value, "force_launches": f_n.value, "update_ms": u_ms.value,
-                "update_launches": u_n.value}
+        """HIP-event totals since the last read: sums of per-launch durations (ms) and launch counts of the force kernel,
+        the update kernels and, in the pair-once mode, the diagonal-tile kernel (``aux``)."""
+        out = (ctypes.c_double * 6)()
+        check(self._lib.nbody_timing_read_ex(self._ctx, out), self._ctx)
+        return {"force_ms": out[0], "force_launches": int(out[1]), "update_ms": out[2], "update_launches": int(out[3]),
+                "aux_ms": out[4], "aux_launches": int(out[5])}
 
     def set_force_mode(self, mode: str) -> None:
         """``"one_sided"`` (default) or ``"symmetric"`` (the pair-once kernel; create the system with

@@ -1,0 +1,184 @@
+"""GPU: the library-owned multi-GPU step (nbody_multi_*, csrc/nbody_multi.hip) with the real HIP kernels.
+
+A one-GPU box cannot run RCCL between ranks (RCCL refuses two ranks on one device), so several shards on cuda:0 exchange
+through NBODY_TRANSPORT_PEER_COPY -- the same streams, events, launch order and hazards, hipMemcpyPeerAsync in place of
+the collective -- and must end with the bits of ONE context on the same padded system.  The RCCL leg itself runs with
+the one rank the box has: communicator set-up, the in-place all-gather, the asynchronous-error poll."""
+import numpy as np
+import pytest
+
+from conftest import rel_state_error
+
+pytestmark = pytest.mark.gpu
+
+DT, EPS = 1e-3, 1e-3
+
+
+def one_context(nb, pos, vel, n_padded, split_len, steps, force_mode="one_sided", integrator="kick_drift", eps_pp=None):
+    """The same padded body set on ONE context: what P shards must reproduce bit for bit."""
+    p = np.zeros((n_padded, 4), dtype=np.float32)
+    v = np.zeros((n_padded, 4), dtype=np.float32)
+    p[:pos.shape[0]], v[:vel.shape[0]] = pos, vel
+    with nb.NBodySystem(n_padded, split_len=split_len) as s:
+        s.set_force_mode(force_mode)
+        s.set_integrator(integrator)
+        if eps_pp is not None:
+            e = np.zeros(n_padded, dtype=np.float32)
+            e[:eps_pp.shape[0]] = eps_pp
+            s.set_particle_softening(e)
+        s.setParticlesPosition(p)
+        s.setParticlesVelocity(v)
+        s.step_n(steps, DT, EPS)
+        pp, vv = s.download()
+        e = s.energy(EPS)
+        mom = s.momentum()
+    n = pos.shape[0]
+    return pp[:n], vv[:n], e, mom
+
+
+@pytest.mark.parametrize("world,force_mode,exchange,integrator", [
+    (2, "one_sided", "allgather", "kick_drift"), (2, "one_sided", "ring", "kick_drift"), (3, "one_sided", "ring", "kdk"),
+    (2, "pair_once", "allgather", "kick_drift"), (2, "pair_once", "ring", "kdk"), (4, "pair_once", "allgather", "kdk"),
+    (8, "pair_once", "ring", "kick_drift")])
+def test_shards_on_one_gpu_reproduce_one_context_bit_for_bit(world, force_mode, exchange, integrator):
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 40000, 3                 # not a multiple of anything: exercises the zero-mass padding
+    split = 512 if force_mode == "pair_once" else 0
+    pos, vel = nb.plummer(n, seed=4321)
+    with MultiGpuSystem(n, devices=[0] * world, force_mode=force_mode, integrator=integrator, exchange=exchange,
+                        transport="peer_copy", split_len=split) as m:
+        assert m.world_size == world and m.local_ranks == world and m.info()["rccl_ranks"] == 0
+        m.set_state(pos, vel)
+        m.step(DT, EPS)                 # one synchronous step, then the rest back to back (exchange in flight)
+        m.step_n(steps - 1, DT, EPS)
+        p, v = m.download()
+        e, mom = m.energy(EPS), m.momentum()
+        assert m.replicas_identical()
+        n_padded, split_len = m.n_padded, m.split_len
+    want_p, want_v, want_e, want_mom = one_context(nb, pos, vel, n_padded, split_len, steps, force_mode, integrator)
+    assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
+    assert np.allclose(e, want_e, rtol=1e-9) and np.allclose(mom, want_mom, rtol=1e-9, atol=1e-12)
+
+
+def test_rccl_leg_with_the_one_rank_this_box_has(oracle_mod):
+    """ncclCommInitAll / ncclCommInitRank, the in-place ncclAllGather (a no-op copy with one rank is never issued: world 1
+    skips the exchange, so the communicator is exercised by the diagnostics' collectives) and the error poll."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem, unique_id
+    n, steps = 8192, 2
+    pos, vel = nb.plummer(n, seed=77)
+    pr, vr = oracle_mod.step_f32(pos, vel, DT, EPS, nsteps=steps)
+    want = None
+    for make in (lambda: MultiGpuSystem(n, devices=[0], transport="rccl"),
+                 lambda: MultiGpuSystem(n, devices=[0], transport="rccl", _rank=0, _world_size=1, _unique_id=unique_id())):
+        with make() as m:
+            assert m.info()["rccl_ranks"] == 1 and m.world_size == 1
+            m.set_state(pos, vel)
+            m.step_n(steps, DT, EPS)
+            p, v = m.download()
+            assert m.replicas_identical()
+            e = m.energy(EPS)
+        assert rel_state_error(p, pr) < 1e-6 and rel_state_error(v, vr) < 1e-6
+        if want is None:
+            want = (p, v, e)
+        else:
+            assert np.array_equal(p, want[0]) and np.array_equal(v, want[1]) and np.array_equal(e, want[2])
+
+
+def test_from_torch_distributed_without_a_process_group_is_one_rank():
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.sharded import sharded_system
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n = 5000
+    pos, vel = nb.plummer(n, seed=5)
+    s = sharded_system(n, device=0, force_mode="pair_once")
+    assert isinstance(s, MultiGpuSystem) and s.world_size == 1
+    s.setParticlesPosition(pos)
+    s.setParticlesVelocity(vel)
+    s.step_n(2, DT, EPS)
+    p, v = s.download()
+    n_padded, split_len = s.n_padded, s.split_len
+    s.close()
+    want_p, want_v, _, _ = one_context(nb, pos, vel, n_padded, split_len, 2, "pair_once")
+    assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
+
+
+def test_particle_softening_and_timing_views_on_shards():
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 12000, 2
+    pos, vel = nb.plummer(n, seed=9)
+    eps_pp = (np.random.default_rng(3).random(n) * 0.02).astype(np.float32)
+    with MultiGpuSystem(n, devices=[0, 0], transport="peer_copy") as m:
+        m.set_state(pos, vel)
+        m.set_particle_softening(eps_pp)
+        for i in range(2):
+            m.shard(i).timing(True)
+        m.step_n(steps, DT, EPS)
+        p, v = m.download()
+        tm = [m.shard(i).read_timing() for i in range(2)]
+        info = m.kernels.device_info()
+        n_padded, split_len = m.n_padded, m.split_len
+    assert "gfx950" in info["name"]
+    for t in tm:                        # own chunk + complement per step, one update per step
+        assert t["force_launches"] == 2 * steps and t["update_launches"] == steps and t["force_ms"] > 0
+    want_p, want_v, _, _ = one_context(nb, pos, vel, n_padded, split_len, steps, eps_pp=eps_pp)
+    assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
+
+
+def test_a_step_that_outlasts_the_timeout_is_reported_not_waited_for():
+    """Failure detection: a wait longer than the timeout returns NBODY_ERR_DEVICE with a message (a dead peer looks like
+    this from the survivor's side) instead of hanging."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd import _lib
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n = 1 << 18
+    pos, vel = nb.plummer(n, seed=1)
+    with MultiGpuSystem(n, devices=[0, 0], transport="peer_copy") as m:
+        m.set_state(pos, vel)
+        m.step(DT, EPS)                 # warm: allocations, kernel load
+        m.set_timeout(1e-3)             # a step takes ~15 ms at this size
+        with pytest.raises(_lib.NBodyError) as e:
+            m.step_n(3, DT, EPS)
+        assert e.value.status == _lib.NBODY_ERR_DEVICE and "timed out" in str(e.value)
+        m.set_timeout(600.0)
+        m.sync()                        # the device work itself was fine and drains
+
+
+@pytest.mark.parametrize("force_mode", ["pair_once", "one_sided"])
+def test_headline_size_two_shards_on_one_gpu_equal_one_context(oracle_mod, force_mode):
+    """BASELINE configs[2]/[3] at the headline size: N = 2^20, the pair-once mode with 1024-body splits (what bench.py
+    runs), as one context and as two shards with the library-owned exchange: the same bits; the accelerations of sampled
+    rows agree with the fp64 oracle and the total force vanishes."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 1 << 20, 2
+    pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
+    with MultiGpuSystem(n, devices=[0, 0], force_mode=force_mode, transport="peer_copy") as m:
+        assert m.split_len == (1024 if force_mode == "pair_once" else 8192) and m.n_padded == n and m.chunk == n // 2
+        m.set_state(pos, vel)
+        m.step_n(steps, DT, EPS)
+        p, v = m.download()
+        assert m.replicas_identical()
+        split_len = m.split_len
+    with nb.NBodySystem(n, split_len=split_len) as s:
+        s.set_force_mode(force_mode)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(steps, DT, EPS)
+        p2, v2 = s.download()
+        assert np.array_equal(p, p2) and np.array_equal(v, v2)
+        # size-independent properties of one force pass: zero velocities and dt = 1 leave a in the velocity buffer
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(np.zeros_like(vel))
+        s.step(1.0, EPS)
+        p1, v1 = s.download()
+    acc = v1[:, :3].astype(np.float64)
+    for lo, hi in ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n)):
+        a64 = oracle_mod.accel_f64(pos, i0=lo, i1=hi, eps=EPS)
+        assert np.linalg.norm(acc[lo:hi] - a64) / np.linalg.norm(a64) < 1e-5
+    mass = pos[:, 3].astype(np.float64)
+    net = (mass[:, None] * acc).sum(0)
+    assert np.all(np.abs(net) < 1e-5 * (mass[:, None] * np.abs(acc)).sum(0))      # Newton's third law over 1.1e12 pairs
+    assert np.array_equal(p1[:, 3], pos[:, 3]) and np.all(v1[:, 3] == 0)

@@ -309,6 +309,58 @@ def test_bad_arguments(nb):
             s.setParticlesPosition(np.zeros((5, 4), np.float32))
 
 
+    with nb.NBodySystem(512) as s:                                   # 0 < eps < 1e-9: eps^-3 x mass would overflow fp32
+        with pytest.raises(nb.NBodyError) as e:
+            s.step(1e-3, 1e-12)
+        assert "softening" in str(e.value)
+        s.step(1e-3, 1e-9)                                            # the smallest accepted length
+        s.step(1e-3, 0.0)                                             # and exactly 0
+    # pair-once shards own whole splits: rows that end in the middle of one are refused (the diagonal tile would write
+    # past the context's rows)
+    with nb.NBodySystem(200, row_lo=0, row_count=100, split_len=256) as s:
+        with pytest.raises(nb.NBodyError) as e:
+            s.set_force_mode("pair_once")
+        assert "split boundary" in str(e.value)
+    with nb.NBodySystem(4096, row_lo=0, row_count=1000, split_len=256) as s:
+        with pytest.raises(nb.NBodyError):
+            s.set_force_mode("pair_once")
+    with nb.NBodySystem(200, row_lo=0, row_count=200, split_len=256) as s:   # ending at n_total is fine
+        s.set_force_mode("pair_once")
+
+
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
+@pytest.mark.parametrize("heavy", [1.0e3, 1.0e10])
+def test_zero_softening_is_safe_for_any_finite_mass(nb, oracle_mod, mode, heavy):
+    """softening = 0 with heavy bodies: the self pair and coincident bodies contribute exactly 0 (a clamp of r^2 instead
+    would give m x 1e36 = inf and 0 x inf = NaN in every sum).  Every kernel variant against the oracle, whose pair
+    function returns 0 at zero distance (oracle/nbody_oracle.c, pair_f32)."""
+    n = 3000
+    pos, vel = nb.uniform_cube(n, seed=21, random_masses=True)
+    pos[:, 3] *= heavy * n                             # masses in [0.5, 1.5] x heavy
+    pos[7] = pos[8]                                    # coincident bodies, same split
+    pos[9, :3] = pos[2000, :3]                         # coincident bodies, different splits
+    pos[11, 3] = np.float32(3.0e38)                    # close to FLT_MAX, but far from everybody
+    pos[11, :3] = (50.0, 60.0, 70.0)
+    want = oracle_mod.accel_f64(pos, eps=0.0)
+    assert np.all(np.isfinite(want))
+    got = {}
+    for rpl in ((0, 1, 2, 8, 40, -4) if mode == "one_sided" else (0,)):
+        with nb.NBodySystem(n, split_len=256 if mode == "pair_once" else 0) as s:
+            s.set_force_mode(mode)
+            s.set_rows_per_lane(rpl)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(np.zeros_like(vel))
+            s.step(1.0, 0.0)
+            got[rpl] = s.download()[1][:, :3]
+            e = s.energy(0.0)
+        assert np.all(np.isfinite(got[rpl])) and np.all(np.isfinite(e))
+        err = np.linalg.norm(got[rpl] - want, axis=1) / np.linalg.norm(want, axis=1)
+        assert err.max() < 1e-4 and np.sqrt((err ** 2).mean()) < TOL
+        assert np.array_equal(got[rpl], got[0])        # every register blocking: the same bits
+    a = got[0]
+    assert np.array_equal(a[7], a[8])                  # coincident bodies feel the same force, none from each other
+
+
 # ---- diagnostics -----------------------------------------------------------------------------------
 
 def test_energy_and_momentum_match_oracle(nb, oracle_mod):
