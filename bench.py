@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+With --gpus N > 1 and no WORLD_SIZE in the environment, bench.py starts the N ranks itself (a torch.distributed.run child,
+before this process touches a GPU) and relays rank 0's line; it exits non-zero if fewer than N devices or ranks come up.
+
 A "step" is one pass of the hot path (the forces of all N x N ordered body-body interactions + kick-drift
 update) over one synthetic Plummer-sphere state resident in HBM.  Rank 0 prints ONE JSON line.
 
@@ -20,7 +23,9 @@ update) over one synthetic Plummer-sphere state resident in HBM.  Rank 0 prints 
               when one exists for this kernel and size, else null.
 * cpu_baseline = the CPU oracle's scalar all-pairs loop (a port; the reference has no CPU path), timed on this
               host's cores on a row slab of the same workload (N = 1 run only).
-Multi-GPU: total N is fixed, rows are sharded over the ranks => "scaling": "strong".
+Multi-GPU: total N is fixed, rows are sharded over the ranks => "scaling": "strong".  With the nccl backend (the product
+path) every per-step exchange runs inside the library (nbody_multi_*, csrc/nbody_multi.hip: RCCL all-gather or ring);
+torch.distributed carries the RCCL id at start-up, the barriers and the max over ranks of the elapsed time.
 """
 import argparse
 import glob
@@ -76,11 +81,14 @@ def cpu_baseline(pos, softening, target_seconds):
 
 def reference_size_leg(nb):
     """The only timing the reference publishes: "1.6 ms" per step for its final VERSION 3 on an RTX 4090
-    (kernel.cu:73), most plausibly at galaxy_20K's N = 20000 padded to 20225.  The same
-    size here, with the reference's dt and effective softening; side information, not the headline metric."""
+    (kernel.cu:73), most plausibly on its default-able dataset 0, galaxy_20K.bin.  The same
+    input here -- the file itself (tests/golden/galaxy_20K.bin, load_data(0), kernel.cu:975-981), padded the reference's
+    way to 20225 bodies (:260-278), its dt and effective softening; side information, not the headline metric."""
     import torch
-    n = 20000
-    pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[1])
+    from n_body_problem_amd import datasets
+    path = os.path.join(ROOT, "tests", "golden", "galaxy_20K.bin")
+    pos, vel = datasets.read_tipsy(path)
+    n = pos.shape[0]
     ppos, pvel = nb.pad_reference_style(pos, vel)            # the reference's 20225-body buffers
     s = nb.NBodySystem(ppos.shape[0])
     s.setParticlesPosition(ppos)
@@ -93,7 +101,8 @@ def reference_size_leg(nb):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / k
     s.close()
-    return {"n_bodies": n, "n_padded": int(ppos.shape[0]), "ms_per_step": ms, "interactions_per_s": float(n) * n / (ms * 1e-3),
+    return {"input": "tests/golden/galaxy_20K.bin (the reference's data/galaxy_20K.bin)", "n_bodies": n,
+            "n_padded": int(ppos.shape[0]), "ms_per_step": ms, "interactions_per_s": float(n) * n / (ms * 1e-3),
             "reference_ms_per_step": 1.6, "reference_hardware": "RTX 4090 (source comment kernel.cu:73, N inferred)",
             "speedup_vs_reference_comment": 1.6 / ms}
 
@@ -119,7 +128,8 @@ def roofline(mode, n, split_len, rows_here, steps, tm):
     traffic = committed_traffic(n, KERNEL_NAME[mode]) if rows_here == n else None
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-            "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
+            "traffic": traffic[0] if traffic else None,
+            "traffic_source": ("committed rocprofv3 PMC summary profiles/" + traffic[1] + " (not measured in this run)") if traffic else None,
             "kernel": KERNEL_NAME[mode],
             "flop_per_launch": FLOP_PER_INTERACTION * executed / launches,
             "executed_pair_evaluations_per_s": executed / force_s,
@@ -172,6 +182,44 @@ def committed_traffic(n, kernel):
     return best
 
 
+def launch_ranks(args):
+    """--gpus N without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) from a parent that
+    never touches a GPU, relay their output and return the exit code -- non-zero when fewer than N devices are visible,
+    a rank fails, or rank 0's line does not report n_gpus = N."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+    if not args.single_device and have < args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but {have} device(s) visible")
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("bench.py: launching", " ".join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in res.stdout.splitlines():
+        if out.startswith("{"):
+            try:
+                if "metric" in json.loads(out):
+                    line = out
+                    continue
+            except ValueError:
+                pass
+        log(out)
+    if res.returncode != 0:
+        log(f"bench.py: the ranks exited with code {res.returncode}")
+        return res.returncode
+    if line is None or json.loads(line).get("n_gpus") != args.gpus:
+        log("bench.py: rank 0 printed no result line for the requested rank count")
+        return 3
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,24 +243,31 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
     mode = "pair_once" if args.force_mode == "symmetric" else args.force_mode
-    if mode == "pair_once" and 8 % max(int(os.environ.get("WORLD_SIZE", "1")), 1):
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))           # before anything here touches a GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different job")
+    if mode == "pair_once" and 8 % world:
         log("the pair-once mode shards over 1, 2, 4 or 8 ranks: falling back to --force-mode one_sided")
         mode = "one_sided"
 
     import torch
     import torch.distributed as dist
     import n_body_problem_amd as nb
-    from n_body_problem_amd.sharded import ShardedNBodySystem
+    from n_body_problem_amd.sharded import sharded_system
+    from n_body_problem_amd.multi import MultiGpuSystem
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     if args.single_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} devices")
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -227,8 +282,13 @@ def main():
         system.set_force_mode(mode)
         kernels = system
     else:
-        system = ShardedNBodySystem(n, device=local_rank, exchange=args.exchange, force_mode=mode)
+        # nccl backend: MultiGpuSystem, the exchange inside the library; gloo: the host-staged rehearsal harness
+        system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode)
         kernels = system.kernels
+    library_exchange = isinstance(system, MultiGpuSystem)
+    rccl_ranks = system.info()["rccl_ranks"] if library_exchange else None
+    if library_exchange and rccl_ranks != world:
+        raise SystemExit(f"bench.py: the RCCL communicator has {rccl_ranks} ranks, expected {world}")
     kernels.set_rows_per_lane(args.rows_per_lane)
     system.setParticlesPosition(pos)
     system.setParticlesVelocity(vel)
@@ -263,15 +323,19 @@ def main():
     sanity = None
     if not args.no_sanity:
         e_after = system.energy(args.softening)
-        digest = system.positions.view(torch.int32).to(torch.int64).sum().reshape(1)
-        lo, hi = digest.clone(), digest.clone()
-        if world > 1:
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if library_exchange:
+            identical = system.replicas_identical()
+        else:
+            digest = system.positions.view(torch.int32).to(torch.int64).sum().reshape(1)
+            lo, hi = digest.clone(), digest.clone()
+            if world > 1:
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            identical = int(lo.item()) == int(hi.item())
         sanity = {"energy_before": float(e_before[2]), "energy_after": float(e_after[2]),
                   "dE_over_E0": float((e_after[2] - e_before[2]) / abs(e_before[2])),
                   "steps_between": args.warmup + args.steps,
-                  "position_replicas_identical_on_all_ranks": bool(int(lo.item()) == int(hi.item()))}
+                  "position_replicas_identical_on_all_ranks": bool(identical)}
 
     out = None
     if rank == 0:
@@ -296,11 +360,15 @@ def main():
                        "n_bodies": n, "parallelism": f"rows sharded x{world}" if world > 1 else "1 GPU",
                        "exchange": args.exchange if world > 1 else None,
                        "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+                       "exchange_owner": ("library (nbody_multi_*, csrc/nbody_multi.hip)" if library_exchange else
+                                          "torch.distributed rehearsal harness") if world > 1 else None,
+                       "rccl_ranks": rccl_ranks,
                        "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3],
                        "force_mode": mode},
             "roofline": roofline(mode, n, int(getattr(system, "split_len", 0)), rows_here, args.steps, tm),
             "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
             "update_ms_per_step": tm["update_ms"] / args.steps,
+            "diagonal_tiles_ms_per_step": tm.get("aux_ms", 0.0) / args.steps,
             "device": info,
             "sanity": sanity,
         }

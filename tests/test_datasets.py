@@ -78,3 +78,19 @@ def test_reference_files_known_answers():
     p, v = ds.load_reference_dataset(5, REF_DATA)              # k17hp.snap through the .snap parser
     assert p.shape == (10002, 4) and p[0, 3] == pytest.approx(2e-4)
     assert ic.padded_count(20000) == 20225                     # the count the reference hard-codes at kernel.cu:1130
+
+
+def test_committed_galaxy_file_against_the_reference_csv_rows(golden_dir):
+    """The reference's own input (load_data(0), kernel.cu:975-981) travels with the repo as a DATA fixture; nine rows of
+    the CSV dump the reference keeps beside it (written by its unused_files/tool.cpp) are the known answer."""
+    pos, vel = ds.read_tipsy(os.path.join(golden_dir, "galaxy_20K.bin"))
+    assert pos.shape == (20000, 4) and vel.shape == (20000, 4)
+    rows = list(csv.reader(open(os.path.join(golden_dir, "galaxy_20k_sample.csv"))))[1:]
+    assert len(rows) == 9
+    for r in rows:
+        i = int(r[0])
+        want = np.array([float(x) for x in r[2:]])              # x,y,z,mass,vx,vy,vz,eps after the CSV's own index
+        got = np.array([*pos[i, :3], pos[i, 3], *vel[i, :3], vel[i, 3]], dtype=np.float64)
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-12), i
+    assert len(np.unique(pos[:, 3])) == 3                       # three mass species: halo, bulge, disk
+    assert ic.padded_count(pos.shape[0]) == 20225               # kernel.cu:1130

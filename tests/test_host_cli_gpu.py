@@ -108,3 +108,32 @@ def test_cli_pair_once_and_kdk_flags_match_the_python_mirror(tmp_path):
             s.step_n(4, 1e-3, 1e-3)
             want_p, want_v = s.download()
         assert np.array_equal(p, want_p) and np.array_equal(v, want_v), flags
+
+
+def test_cli_devices_runs_the_library_owned_multi_gpu_step(tmp_path):
+    """nbody_run --devices: the C++ host drives nbody_multi_* (both ranks on cuda:0, peer copies standing in for RCCL,
+    which refuses duplicate devices) and ends with the bits of the single-context run on the same padded system."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd import datasets as ds
+    from n_body_problem_amd.multi import geometry
+    n = 6000
+    pos, vel = nb.plummer(n, seed=92)
+    start = str(tmp_path / "start.nbs")
+    ds.save_snapshot(start, pos, vel, step=0, time=0.0)
+    for flags, mode in ((["--pair-once"], "pair_once"), ([], "one_sided"), (["--ring", "--kdk"], "one_sided")):
+        out = run_cli("--resume", start, "--steps", 4, "--dt", 1e-3, "--softening", 1e-3, "--energy-every", 2, "--devices", "0,0",
+                      "--peer-copy", *flags, "--final", tmp_path / "multi.nbs")
+        assert "replicas identical: yes" in out and "ranks = 2" in out and "dE/E0" in out
+        p, v, step, _ = ds.load_snapshot(str(tmp_path / "multi.nbs"))
+        n_padded, _, split_len = geometry(n, 2, mode)
+        pp = np.zeros((n_padded, 4), np.float32)
+        vv = np.zeros((n_padded, 4), np.float32)
+        pp[:n], vv[:n] = pos, vel
+        with nb.NBodySystem(n_padded, split_len=split_len) as s:
+            s.set_force_mode(mode)
+            s.set_integrator("kdk" if "--kdk" in flags else "kick_drift")
+            s.setParticlesPosition(pp)
+            s.setParticlesVelocity(vv)
+            s.step_n(4, 1e-3, 1e-3)
+            want_p, want_v = s.download()
+        assert step == 4 and np.array_equal(p, want_p[:n]) and np.array_equal(v, want_v[:n]), flags

@@ -174,6 +174,24 @@ def test_reference_constants_and_padding(nb, oracle_mod, mode):
     assert rel_state_error(pp[:n], p3[:n]) < TOL and rel_state_error(vp[:n], v3[:n]) < TOL
 
 
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
+def test_reference_dataset_galaxy_20k_ten_steps(nb, oracle_mod, golden_dir, mode):
+    """The reference's own workload, load_data(0) (kernel.cu:975-981): data/galaxy_20K.bin (three mass species, real
+    close pairs), padded its way to 20 225 bodies (:260-278), dt = 0.008 and VERSION 3's effective softening (:63-66,
+    665-692), ten frames of the bracket :1225-1242 -- against the oracle's literal restatement of VERSION 3."""
+    import os
+    from n_body_problem_amd import datasets as ds
+    pos, vel = ds.read_tipsy(os.path.join(golden_dir, "galaxy_20K.bin"))
+    n = pos.shape[0]
+    ppos, pvel = nb.pad_reference_style(pos, vel)
+    assert n == 20000 and ppos.shape[0] == 20225
+    p, v = run_gpu(nb, ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 10, mode)
+    p3, v3 = oracle_mod.step_v3(ppos, pvel, nsteps=10)
+    assert rel_state_error(p[:n], p3[:n]) < TOL and rel_state_error(v[:n], v3[:n]) < TOL
+    assert np.array_equal(p[:, 3], ppos[:, 3])          # masses untouched
+    assert np.array_equal(v[:, 3], pvel[:, 3])          # the eps column the reference loads and never reads: preserved
+
+
 # ---- bit-exact invariances -----------------------------------------------------------------------
 
 def test_register_blocking_is_bit_exact(nb):

@@ -6,7 +6,8 @@ and interactions/s).  One process per GPU:
         --bodies 4194304 --steps 1000 --energy-every 100
     python tools/run_sharded.py --bodies 131072 --steps 1000 --energy-every 100          # one GPU
 
-Rank 0 prints one line per report and a final JSON summary."""
+Rank 0 prints one line per report and a final JSON summary.  Each energy report is an O(N^2) potential pass of its own
+(one row per lane: about the cost of two force passes at N = 2^22), outside the timed steps."""
 import argparse
 import json
 import os
@@ -34,7 +35,7 @@ def main():
     import torch
     import torch.distributed as dist
     import n_body_problem_amd as nb
-    from n_body_problem_amd.sharded import ShardedNBodySystem
+    from n_body_problem_amd.sharded import sharded_system
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -46,8 +47,9 @@ def main():
             dist.init_process_group("gloo")
     n = args.bodies
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[5])
-    s = ShardedNBodySystem(n, device=local, exchange=args.exchange, force_mode=args.force_mode, integrator=args.integrator,
-                           split_len=args.split_len)
+    # nccl backend (or a single process): the exchange runs inside the library (nbody_multi_*); gloo: the rehearsal harness
+    s = sharded_system(n, device=local, exchange=args.exchange, force_mode=args.force_mode, integrator=args.integrator,
+                       split_len=args.split_len)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel)
     del pos, vel
