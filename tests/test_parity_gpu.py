@@ -174,20 +174,46 @@ def test_reference_constants_and_padding(nb, oracle_mod, mode):
     assert rel_state_error(pp[:n], p3[:n]) < TOL and rel_state_error(vp[:n], v3[:n]) < TOL
 
 
+_GALAXY = {}
+
+
+def galaxy_oracle(nb, oracle_mod, golden_dir):
+    """The reference's own input and what the CPU paths make of it (computed once per session)."""
+    if not _GALAXY:
+        import os
+        from n_body_problem_amd import datasets as ds
+        pos, vel = ds.read_tipsy(os.path.join(golden_dir, "galaxy_20K.bin"))
+        ppos, pvel = nb.pad_reference_style(pos, vel)
+        _GALAXY.update(n=pos.shape[0], ppos=ppos, pvel=pvel,
+                       v3_1=oracle_mod.step_v3(ppos, pvel, nsteps=1), v3_10=oracle_mod.step_v3(ppos, pvel, nsteps=10),
+                       f64_10=oracle_mod.step_f64(ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, nsteps=10))
+    return _GALAXY
+
+
 @pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
 def test_reference_dataset_galaxy_20k_ten_steps(nb, oracle_mod, golden_dir, mode):
     """The reference's own workload, load_data(0) (kernel.cu:975-981): data/galaxy_20K.bin (three mass species, real
     close pairs), padded its way to 20 225 bodies (:260-278), dt = 0.008 and VERSION 3's effective softening (:63-66,
-    665-692), ten frames of the bracket :1225-1242 -- against the oracle's literal restatement of VERSION 3."""
-    import os
-    from n_body_problem_amd import datasets as ds
-    pos, vel = ds.read_tipsy(os.path.join(golden_dir, "galaxy_20K.bin"))
-    n = pos.shape[0]
-    ppos, pvel = nb.pad_reference_style(pos, vel)
+    665-692), ten frames of the bracket :1225-1242 -- against the oracle's literal restatement of VERSION 3.
+
+    On THIS input fp32 summation order matters more than on the synthetic spheres: bodies beside a heavy halo particle
+    carry partial sums of ~100 in an acceleration of ~10, the reference-order fp32 accelerations are 9e-6 (relative L2)
+    off the fp64 truth, and summing the columns in descending instead of ascending order moves the oracle's own
+    velocities by 5.6e-5 after ten frames (the reference's float atomics, kernel.cu:758-773, pick a different order on
+    every run).  So: one frame within 1e-5; ten frames -- positions within 1e-5, velocities no further from the fp64
+    truth than the reference-order fp32 path is, and within that spread of it."""
+    g = galaxy_oracle(nb, oracle_mod, golden_dir)
+    n, ppos, pvel = g["n"], g["ppos"], g["pvel"]
     assert n == 20000 and ppos.shape[0] == 20225
+    p1, v1 = run_gpu(nb, ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 1, mode)
+    assert rel_state_error(p1[:n], g["v3_1"][0][:n]) < TOL and rel_state_error(v1[:n], g["v3_1"][1][:n]) < TOL
     p, v = run_gpu(nb, ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, 10, mode)
-    p3, v3 = oracle_mod.step_v3(ppos, pvel, nsteps=10)
-    assert rel_state_error(p[:n], p3[:n]) < TOL and rel_state_error(v[:n], v3[:n]) < TOL
+    (p3, v3), (p64, v64) = g["v3_10"], g["f64_10"]
+    assert rel_state_error(p[:n], p3[:n]) < TOL
+    oracle_vs_truth = rel_state_error(v3[:n], v64[:n])
+    assert 1e-5 < oracle_vs_truth < 2e-4                  # the fp32 reference order itself: ~5e-5 here
+    assert rel_state_error(v[:n], v64[:n]) < 1.25 * oracle_vs_truth
+    assert rel_state_error(v[:n], v3[:n]) < 2.5 * oracle_vs_truth
     assert np.array_equal(p[:, 3], ppos[:, 3])          # masses untouched
     assert np.array_equal(v[:, 3], pvel[:, 3])          # the eps column the reference loads and never reads: preserved
 
