@@ -198,6 +198,16 @@ int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);
  * compiler-allocated loop).  Never changes a result bit. */
 int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
 
+/* Equal-mass splits (on by default).  Before every force launch an O(N) pass notes, per split, whether all its bodies
+ * carry one mass (every split of an equal-mass system such as the benchmark's Plummer sphere; most splits of a
+ * few-species file like galaxy_20K.bin).  Such a split's inner loop leaves the mass out -- the sums collect d x inv^3 and
+ * are multiplied by the mass once when they are written -- which saves one of 12 fp32 instructions per interaction in the
+ * one-sided kernels and two of 16 per pair in the pair-once tiles (both sides of the tile must qualify).  The choice is
+ * a function of the data and of the split boundaries only, so every invariance stays bit-exact (register blocking, row
+ * sharding, column ranges, GPU count); against the general path the results differ by rounding (m x sum instead of
+ * sum of m x term).  0 switches it off: every split takes the general path (A/B measurement, tests). */
+int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
+
 /* Device facts for the roofline: out = {compute units, max clock MHz, wavefront size, LDS bytes per CU}. */
 int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);
 

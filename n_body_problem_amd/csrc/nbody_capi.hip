@@ -20,6 +20,7 @@ struct nbody_ctx {
     int64_t n_total = 0, row_lo = 0, row_count = 0, split_len = 0;
     int n_splits = 0;
     int rows_per_lane = 0;  // 0 = pick per launch
+    bool equal_mass_path = true;  // splits whose bodies share one mass take the inner loop without mass multiplies
     int force_mode = NBODY_FORCE_ONE_SIDED;
     int integrator = NBODY_INTEGRATOR_KICK_DRIFT;
     float4 *acc = nullptr;      // kick-drift-kick mode: accelerations of the own rows at the current positions
@@ -33,6 +34,7 @@ struct nbody_ctx {
     float4 *colparts = nullptr;      // [kSymGroups][n_total] in use: the caller's (nbody_sym_set_colparts) or colparts_own
     float4 *colparts_own = nullptr;
     float4 *sym_acc = nullptr;       // [row_count]: the summed accelerations the update kernels read as one split
+    float *split_mass = nullptr;     // [n_splits]: the one mass of each split's bodies or NaN (pair-once tiles' fast path)
     bool sym_reduced = false;        // nbody_sym_reduce has run since the last forces
     int group_splits = 1, group_lo = 0, group_count = 0;
     int cu_count = 256;
@@ -184,6 +186,8 @@ int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row
     size_t red = (size_t)std::max(1, energy_blocks((int)row_count)) * 4;
     if (rc == NBODY_OK)
         guard(hipMalloc((void **)&c->reduce_dev, red * sizeof(double)), "hipMalloc(reduce)");
+    if (rc == NBODY_OK)
+        guard(hipMalloc((void **)&c->split_mass, sizeof(float) * (size_t)std::max(1, c->n_splits)), "hipMalloc(split_mass)");
     c->reduce_host.resize(red);
     if (rc != NBODY_OK) {
         nbody_destroy(c);
@@ -221,6 +225,7 @@ int nbody_destroy(nbody_ctx *c)
     if (c->col_partials) (void)hipFree(c->col_partials);
     if (c->colparts_own) (void)hipFree(c->colparts_own);
     if (c->sym_acc) (void)hipFree(c->sym_acc);
+    if (c->split_mass) (void)hipFree(c->split_mass);
     if (c->acc) (void)hipFree(c->acc);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -452,6 +457,7 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
                                             "split_len needs less)");
         if (!c->sym_acc && c->row_count)
             HIP_TRY(c, hipMalloc((void **)&c->sym_acc, sizeof(float4) * (size_t)c->row_count));
+
         if (!c->colparts) {
             if (!c->colparts_own && c->n_total)
                 HIP_TRY(c, hipMalloc((void **)&c->colparts_own, sizeof(float4) * (size_t)kSymGroups * (size_t)c->n_total));
@@ -560,6 +566,15 @@ int nbody_upload_particle_softening(nbody_ctx *c, const float *h_eps)
     HIP_TRY(c, hipMemcpyAsync(c->eps_own, h_eps, sizeof(float) * (size_t)c->n_total, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return nbody_set_particle_softening(c, c->eps_own);
+}
+
+int nbody_set_equal_mass_path(nbody_ctx *c, int on)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    c->equal_mass_path = on != 0;
+    c->acc_valid = false;
+    return NBODY_OK;
 }
 
 int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
@@ -697,7 +712,9 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.row_count = (int)c->row_count;
         sa.eps2 = softening * softening;
         sa.eps_pp = c->eps_pp;
+        sa.split_mass = c->split_mass;
         HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, launch_split_mass(sa.pos, c->split_mass, sa.n_total, L, c->equal_mass_path, c->stream));
         {
             TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone: rocprofv3's time for it
             HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
@@ -713,6 +730,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return NBODY_OK;
     }
     ForceArgs a;
+    a.split_mass = c->split_mass;
     a.pos = reinterpret_cast<const float4 *>(d_pos);
     a.partials = c->partials;
     a.row_lo = (int)c->row_lo;
@@ -735,6 +753,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
     if (a.split_count <= 0)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_split_mass(a.pos, c->split_mass, a.n_total, a.split_len, c->equal_mass_path, c->stream));
     {
         TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);
         HIP_TRY(c, launch_forces(a, pick_rows_per_lane(c, a.split_count), c->stream));

@@ -28,6 +28,7 @@ struct ForceArgs {
     int skip_count;      //   "every split except a range": split = split_first + y, += skip_count once >= skip_first
     float eps2;          // softening length squared
     const float *eps_pp; // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
+    const float *split_mass;  // [n_splits]: the one mass of a split's bodies, or NaN (launch_split_mass)
 };
 
 // Pair-once kernel (nbody_symmetric.hip): one workgroup per ordered pair of splits (R, C), R's bodies as rows (one
@@ -66,7 +67,10 @@ struct SymArgs {
     int row_lo, row_count; // the context's own rows (whole splits)
     float eps2;
     const float *eps_pp;   // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
+    const float *split_mass;  // [n_splits]: the one mass of a split's bodies, or NaN (launch_split_mass)
 };
+// split_mass[s] for every split of the body set, from the masses now in pos (O(N); see split_mass_kernel)
+hipError_t launch_split_mass(const float4 *pos, float *split_mass, int n_total, int split_len, bool enabled, hipStream_t stream);
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);       // the tiles (R != C)
 hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream);  // the diagonal tiles
 size_t symmetric_lds_bytes(int split_len);

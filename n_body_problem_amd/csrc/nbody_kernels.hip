@@ -12,6 +12,8 @@
 // The kernel is VALU-bound; HBM traffic is the O(N) state plus the partials.
 #include "nbody_kernels.h"
 
+#include <type_traits>
+
 namespace nbody {
 
 // One body-body interaction: 3 sub, 3 fma (r^2+eps^2), 1 rsq, 3 mul, 3 fma = 12 fp32 VALU instructions + 1
@@ -82,6 +84,15 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
         etile[0][tid] = stage_e * stage_e;
     __syncthreads();
 
+    // A split whose bodies all have one mass (ForceArgs::split_mass; every split of an equal-mass system): the mass
+    // leaves the loop -- the sums collect d * inv^3 and are multiplied by it once at the end -- 11 fp32 instructions + 1
+    // transcendental per interaction instead of 12 + 1.  Decided per split from the data, so every register blocking
+    // and every sharding takes the same path for the same split: the variants stay bit-identical among themselves.
+    const float split_mass = (GUARD || PPS) ? __builtin_nanf("") : a.split_mass[split];
+    const bool uniform = split_mass == split_mass;
+
+    auto tiles = [&](auto uniform_tag) {
+    constexpr bool UNIFORM = decltype(uniform_tag)::value;
     for (int t = 0; t < ntiles; ++t) {
         const int jn = j0 + (t + 1) * kTile + tid;
         if (t + 1 < ntiles) {  // in flight under the tile's arithmetic
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {  // phase 4: m_j / (r^2+eps^2)^(3/2) and the accumulation
                 const float inv = w[k];
-                const float s = (pj.w * inv) * (inv * inv);
+                const float s = UNIFORM ? inv * (inv * inv) : (pj.w * inv) * (inv * inv);
                 ax[k] = __builtin_fmaf(dx[k], s, ax[k]);
                 ay[k] = __builtin_fmaf(dy[k], s, ay[k]);
                 az[k] = __builtin_fmaf(dz[k], s, az[k]);
@@ -144,13 +155,19 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
         }
         __syncthreads();
     }
+    };
+    if (uniform)
+        tiles(std::true_type{});
+    else
+        tiles(std::false_type{});
+    const float scale = uniform ? split_mass : 1.f;
 
     float4 *out = a.partials + (size_t)split * a.row_count;
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const int r = row_base + k * kTile;
         if (r < a.row_count)
-            out[r] = make_float4(ax[k], ay[k], az[k], 0.f);
+            out[r] = make_float4(ax[k] * scale, ay[k] * scale, az[k] * scale, 0.f);
     }
 }
 
@@ -172,6 +189,9 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 #define NB_POST(PM, AX, AY, AZ, R, D0, D1, D2, Q)                                                                \
     "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " R ", " PM ", " R "\n\tv_mul_f32_e32 " R ", " R ", " Q "\n\t"     \
     "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t"
+#define NB_POSTU(PM, AX, AY, AZ, R, D0, D1, D2, Q) /* a split of equal masses: see force_kernel */                  \
+    "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " R ", " R ", " Q "\n\t"                                      \
+    "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t"
 // one column: wait for its LDS read, phase 1 for the four rows, the four rsq, issue the NEXT read, idle 24 wait
 // states (20-28 measured equally good on the kernel, 12 and 32 about 2 % worse), phase 4
 // Wave priority (measured after the gap was tuned): priority 2 for the PRE + v_rsq_f32 phases, 0 for the POST phase --
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 #define NB_R4_PRIO_POST "s_setprio 0\n\t"
 #define NB_R4_PRIO_PRE "s_setprio 2\n\t"
 #endif
-#define NB_COLUMN(PX, PY, PZ, PM, NEXT, GRD)                                                                     \
+#define NB_COLUMN(PX, PY, PZ, PM, NEXT, GRD, POST)                                                                     \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
     NB_PRE(PX, PY, PZ, "v9", "v10", "v11", "v36", "v37", "v38", "v39", GRD)                                      \
     NB_PRE(PX, PY, PZ, "v13", "v14", "v15", "v40", "v41", "v42", "v43", GRD)                                     \
@@ -193,20 +213,20 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     NB_PRE(PX, PY, PZ, "v21", "v22", "v23", "v48", "v49", "v50", "v51", GRD)                                     \
     "v_rsq_f32_e32 v36, v36\n\tv_rsq_f32_e32 v40, v40\n\tv_rsq_f32_e32 v44, v44\n\tv_rsq_f32_e32 v48, v48\n\t"       \
     NEXT NB_R4_GAP NB_R4_PRIO_POST                                                                               \
-    NB_POST(PM, "v12", "v25", "v26", "v36", "v37", "v38", "v39", "v33")                                          \
-    NB_POST(PM, "v16", "v27", "v28", "v40", "v41", "v42", "v43", "v34")                                          \
-    NB_POST(PM, "v20", "v29", "v30", "v44", "v45", "v46", "v47", "v33")                                          \
-    NB_POST(PM, "v24", "v31", "v32", "v48", "v49", "v50", "v51", "v34")                                          \
+    POST(PM, "v12", "v25", "v26", "v36", "v37", "v38", "v39", "v33")                                          \
+    POST(PM, "v16", "v27", "v28", "v40", "v41", "v42", "v43", "v34")                                          \
+    POST(PM, "v20", "v29", "v30", "v44", "v45", "v46", "v47", "v33")                                          \
+    POST(PM, "v24", "v31", "v32", "v48", "v49", "v50", "v51", "v34")                                          \
     NB_R4_PRIO_PRE
-#define NB_TILE_LOOP(GRD)                                                                                        \
+#define NB_TILE_LOOP(GRD, POST)                                                                                        \
     NB_R4_PRIO_PRE                                                                                               \
     "ds_read_b128 v[0:3], v52\n\t"                                                                               \
     "s_mov_b32 %[cnt], 64\n"                                                                                     \
     "1:\n\t"                                                                                                     \
-    NB_COLUMN("v0", "v1", "v2", "v3", "ds_read_b128 v[4:7], v52 offset:16\n\t", GRD)                             \
-    NB_COLUMN("v4", "v5", "v6", "v7", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD)                             \
-    NB_COLUMN("v0", "v1", "v2", "v3", "ds_read_b128 v[4:7], v52 offset:48\n\t", GRD)                             \
-    NB_COLUMN("v4", "v5", "v6", "v7", "v_add_u32_e32 v52, 64, v52\n\tds_read_b128 v[0:3], v52\n\t", GRD)          \
+    NB_COLUMN("v0", "v1", "v2", "v3", "ds_read_b128 v[4:7], v52 offset:16\n\t", GRD, POST)                             \
+    NB_COLUMN("v4", "v5", "v6", "v7", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD, POST)                             \
+    NB_COLUMN("v0", "v1", "v2", "v3", "ds_read_b128 v[4:7], v52 offset:48\n\t", GRD, POST)                             \
+    NB_COLUMN("v4", "v5", "v6", "v7", "v_add_u32_e32 v52, 64, v52\n\tds_read_b128 v[0:3], v52\n\t", GRD, POST)          \
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
@@ -226,6 +246,8 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     const int j1 = min(j0 + a.split_len, a.n_total);
     const int ntiles = (j1 - j0 + kTile - 1) / kTile;
     const int row_base = blockIdx.x * (kTile * 4) + tid;
+    const float split_mass = GUARD ? __builtin_nanf("") : a.split_mass[split];  // see force_kernel
+    const bool uniform = split_mass == split_mass;
 
     // pinned for the whole kernel (local register variables): no copies around the asm block, 8 waves per SIMD
     register float x0 asm("v9"), y0 asm("v10"), z0 asm("v11"), ax0 asm("v12");
@@ -281,9 +303,11 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42",   \
           "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "vcc", "memory"
         if (GUARD)
-            asm volatile(NB_TILE_LOOP(NB_GUARD) NB_OPERANDS);
+            asm volatile(NB_TILE_LOOP(NB_GUARD, NB_POST) NB_OPERANDS);
+        else if (uniform)
+            asm volatile(NB_TILE_LOOP(NB_NOGUARD, NB_POSTU) NB_OPERANDS);
         else
-            asm volatile(NB_TILE_LOOP(NB_NOGUARD) NB_OPERANDS);
+            asm volatile(NB_TILE_LOOP(NB_NOGUARD, NB_POST) NB_OPERANDS);
 #undef NB_OPERANDS
         if (t + 1 < ntiles)
             tile[((t + 1) & 1) * kTile + tid] = stage;
@@ -291,8 +315,9 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     }
 
     float4 *out = a.partials + (size_t)split * a.row_count;
-    const float4 r0 = make_float4(ax0, ay0, az0, 0.f), r1 = make_float4(ax1, ay1, az1, 0.f);
-    const float4 r2 = make_float4(ax2, ay2, az2, 0.f), r3 = make_float4(ax3, ay3, az3, 0.f);
+    const float sc = uniform ? split_mass : 1.f;
+    const float4 r0 = make_float4(ax0 * sc, ay0 * sc, az0 * sc, 0.f), r1 = make_float4(ax1 * sc, ay1 * sc, az1 * sc, 0.f);
+    const float4 r2 = make_float4(ax2 * sc, ay2 * sc, az2 * sc, 0.f), r3 = make_float4(ax3 * sc, ay3 * sc, az3 * sc, 0.f);
     if (row_base < a.row_count) out[row_base] = r0;
     if (row_base + kTile < a.row_count) out[row_base + kTile] = r1;
     if (row_base + 2 * kTile < a.row_count) out[row_base + 2 * kTile] = r2;
@@ -327,24 +352,30 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     "v_pk_fma_f32 " AX ", " DX ", " R ", " AX "\n\t"                                                                 \
     "v_pk_fma_f32 " AY ", " DY ", " R ", " AY "\n\t"                                                                 \
     "v_pk_fma_f32 " AZ ", " DZ ", " R ", " AZ "\n\t"
-#define PK_COLUMN(PXY, PZM, NEXT, GRD)                                                                           \
+#define PK_POSTU(PZM, AX, AY, AZ, DX, DY, DZ, R) /* a split of equal masses: see force_kernel */                   \
+    "v_pk_mul_f32 v[54:55], " R ", " R "\n\t"                                                                       \
+    "v_pk_mul_f32 " R ", " R ", v[54:55]\n\t"                                                                       \
+    "v_pk_fma_f32 " AX ", " DX ", " R ", " AX "\n\t"                                                                 \
+    "v_pk_fma_f32 " AY ", " DY ", " R ", " AY "\n\t"                                                                 \
+    "v_pk_fma_f32 " AZ ", " DZ ", " R ", " AZ "\n\t"
+#define PK_COLUMN(PXY, PZM, NEXT, GRD, POST)                                                                           \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
     PK_PRE(PXY, PZM, "v[14:15]", "v[18:19]", "v[12:13]", "v[30:31]", "v[34:35]", "v[38:39]", "v[20:21]", "v20", "v21", GRD) \
     PK_PRE(PXY, PZM, "v[22:23]", "v[26:27]", "v[16:17]", "v[42:43]", "v[46:47]", "v[50:51]", "v[24:25]", "v24", "v25", GRD) \
     "v_rsq_f32_e32 v20, v20\n\tv_rsq_f32_e32 v21, v21\n\tv_rsq_f32_e32 v24, v24\n\tv_rsq_f32_e32 v25, v25\n\t"       \
     NEXT NB_R4_GAP NB_R4_PRIO_POST                                                                               \
-    PK_POST(PZM, "v[28:29]", "v[32:33]", "v[36:37]", "v[30:31]", "v[34:35]", "v[38:39]", "v[20:21]")             \
-    PK_POST(PZM, "v[40:41]", "v[44:45]", "v[48:49]", "v[42:43]", "v[46:47]", "v[50:51]", "v[24:25]")             \
+    POST(PZM, "v[28:29]", "v[32:33]", "v[36:37]", "v[30:31]", "v[34:35]", "v[38:39]", "v[20:21]")             \
+    POST(PZM, "v[40:41]", "v[44:45]", "v[48:49]", "v[42:43]", "v[46:47]", "v[50:51]", "v[24:25]")             \
     NB_R4_PRIO_PRE
-#define PK_TILE_LOOP(GRD)                                                                                        \
+#define PK_TILE_LOOP(GRD, POST)                                                                                        \
     NB_R4_PRIO_PRE                                                                                               \
     "ds_read_b128 v[0:3], v52\n\t"                                                                               \
     "s_mov_b32 %[cnt], 64\n"                                                                                     \
     "1:\n\t"                                                                                                     \
-    PK_COLUMN("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:16\n\t", GRD)                                 \
-    PK_COLUMN("v[4:5]", "v[6:7]", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD)                                 \
-    PK_COLUMN("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:48\n\t", GRD)                                 \
-    PK_COLUMN("v[4:5]", "v[6:7]", "v_add_u32_e32 v52, 64, v52\n\tds_read_b128 v[0:3], v52\n\t", GRD)              \
+    PK_COLUMN("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:16\n\t", GRD, POST)                                 \
+    PK_COLUMN("v[4:5]", "v[6:7]", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD, POST)                                 \
+    PK_COLUMN("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:48\n\t", GRD, POST)                                 \
+    PK_COLUMN("v[4:5]", "v[6:7]", "v_add_u32_e32 v52, 64, v52\n\tds_read_b128 v[0:3], v52\n\t", GRD, POST)              \
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
@@ -366,6 +397,8 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
     const int j1 = min(j0 + a.split_len, a.n_total);
     const int ntiles = (j1 - j0 + kTile - 1) / kTile;
     const int row_base = blockIdx.x * (kTile * 4) + tid;
+    const float split_mass = GUARD ? __builtin_nanf("") : a.split_mass[split];  // see force_kernel
+    const bool uniform = split_mass == split_mass;
 
     float4 p[4];
 #pragma unroll
@@ -406,9 +439,11 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35", "v38",   \
           "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "vcc", "memory"
         if (GUARD)
-            asm volatile(PK_TILE_LOOP(PK_GUARD) PK_OPERANDS);
+            asm volatile(PK_TILE_LOOP(PK_GUARD, PK_POST) PK_OPERANDS);
+        else if (uniform)
+            asm volatile(PK_TILE_LOOP(PK_NOGUARD, PK_POSTU) PK_OPERANDS);
         else
-            asm volatile(PK_TILE_LOOP(PK_NOGUARD) PK_OPERANDS);
+            asm volatile(PK_TILE_LOOP(PK_NOGUARD, PK_POST) PK_OPERANDS);
 #undef PK_OPERANDS
         if (t + 1 < ntiles)
             tile[((t + 1) & 1) * kTile + tid] = stage;
@@ -416,10 +451,11 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
     }
 
     float4 *out = a.partials + (size_t)split * a.row_count;
-    if (row_base < a.row_count) out[row_base] = make_float4(ax01.x, ay01.x, az01.x, 0.f);
-    if (row_base + kTile < a.row_count) out[row_base + kTile] = make_float4(ax01.y, ay01.y, az01.y, 0.f);
-    if (row_base + 2 * kTile < a.row_count) out[row_base + 2 * kTile] = make_float4(ax23.x, ay23.x, az23.x, 0.f);
-    if (row_base + 3 * kTile < a.row_count) out[row_base + 3 * kTile] = make_float4(ax23.y, ay23.y, az23.y, 0.f);
+    const float sc = uniform ? split_mass : 1.f;
+    if (row_base < a.row_count) out[row_base] = make_float4(ax01.x * sc, ay01.x * sc, az01.x * sc, 0.f);
+    if (row_base + kTile < a.row_count) out[row_base + kTile] = make_float4(ax01.y * sc, ay01.y * sc, az01.y * sc, 0.f);
+    if (row_base + 2 * kTile < a.row_count) out[row_base + 2 * kTile] = make_float4(ax23.x * sc, ay23.x * sc, az23.x * sc, 0.f);
+    if (row_base + 3 * kTile < a.row_count) out[row_base + 3 * kTile] = make_float4(ax23.y * sc, ay23.y * sc, az23.y * sc, 0.f);
 }
 
 static hipError_t launch_forces_r4pk(const ForceArgs &a, hipStream_t stream)

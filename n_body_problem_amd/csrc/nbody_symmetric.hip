@@ -31,6 +31,7 @@
 
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 namespace nbody {
@@ -74,6 +75,14 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     "v_mul_f32_e32 " SC ", " M ", " T "\n\tv_mul_f32_e32 " R ", " PM ", " T "\n\t"                                    \
     "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t" \
     "v_fmac_f32_e32 v45, " D0 ", " SC "\n\tv_fmac_f32_e32 v68, " D1 ", " SC "\n\tv_fmac_f32_e32 v49, " D2 ", " SC "\n\t"
+// Tiles whose row bodies all have one mass and whose column bodies all have one mass (SymArgs::split_mass: every tile of
+// an equal-mass system, most tiles of a few-species one): the masses leave the loop -- the sums collect d * inv^3 and
+// are multiplied by the other side's mass once, when they are written out -- which drops the two mass multiplies of a
+// pair: 14 fp32 instructions + 1 transcendental instead of 16 + 1.  inv^3 is built in the register of inv (bank 3).
+#define SY_POSTU(PM, M, AX, AY, AZ, D0, D1, D2, R, Q, T, SC)                                                     \
+    "v_mul_f32_e32 " Q ", " R ", " R "\n\tv_mul_f32_e32 " R ", " R ", " Q "\n\t"                                      \
+    "v_fmac_f32_e32 " AX ", " D0 ", " R "\n\tv_fmac_f32_e32 " AY ", " D1 ", " R "\n\tv_fmac_f32_e32 " AZ ", " D2 ", " R "\n\t" \
+    "v_fmac_f32_e32 v45, " D0 ", " R "\n\tv_fmac_f32_e32 v68, " D1 ", " R "\n\tv_fmac_f32_e32 v49, " D2 ", " R "\n\t"
 // Wave priority: a wave runs its PRE + v_rsq_f32 phases at priority 2 and drops to 0 for the POST phase, so the SIMD
 // issues a waiting wave's rsq batch before another wave's long POST stretch and the wave then sits out its slow window
 //  while the others issue -- measured 1.7-2.3 % faster than equal priorities, and with it the
@@ -93,7 +102,7 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
 // next column's read may not).
 #define SY_ROTATE                                                                                                \
     "ds_bpermute_b32 v45, v59, v45\n\tds_bpermute_b32 v68, v59, v68\n\tds_bpermute_b32 v49, v59, v49\n\t"
-#define SY_STEP(PX, PY, PZ, PM, NEXT, GRD)                                                                       \
+#define SY_STEP(PX, PY, PZ, PM, NEXT, GRD, POST)                                                                       \
     "v_add_u32_e32 v1, 16, v1\n\t"                                                                               \
     "v_and_or_b32 v0, v1, v55, v10\n\t"                                                                          \
     "s_waitcnt lgkmcnt(3)\n\t"                                                                                   \
@@ -106,13 +115,13 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     NB_SYM_GAP                                                                                                   \
     "s_waitcnt lgkmcnt(1)\n\t"                                                                                   \
     NB_SYM_PRIO_POST                                                                                             \
-    SY_POST(PM, "v15", "v53", "v54", "v52", "v28", "v29", "v30", "v31", "v44", "v46", "v47")                     \
-    SY_POST(PM, "v19", "v57", "v58", "v56", "v32", "v33", "v34", "v35", "v48", "v50", "v51")                     \
-    SY_POST(PM, "v23", "v61", "v62", "v60", "v36", "v37", "v38", "v39", "v44", "v46", "v47")                     \
-    SY_POST(PM, "v27", "v65", "v66", "v64", "v40", "v41", "v42", "v43", "v48", "v50", "v51")                     \
+    POST(PM, "v15", "v53", "v54", "v52", "v28", "v29", "v30", "v31", "v44", "v46", "v47")                     \
+    POST(PM, "v19", "v57", "v58", "v56", "v32", "v33", "v34", "v35", "v48", "v50", "v51")                     \
+    POST(PM, "v23", "v61", "v62", "v60", "v36", "v37", "v38", "v39", "v44", "v46", "v47")                     \
+    POST(PM, "v27", "v65", "v66", "v64", "v40", "v41", "v42", "v43", "v48", "v50", "v51")                     \
     NB_SYM_PRIO_PRE                                                                                              \
     SY_ROTATE
-#define SY_GROUP_LOOP(GRD)                                                                                       \
+#define SY_GROUP_LOOP(GRD, POST)                                                                                       \
     "s_waitcnt lgkmcnt(0)\n\t" /* nothing of the compiler's may be counted by the waits below */                 \
     "v_and_or_b32 v0, v1, v55, v10\n\t"                                                                          \
     "ds_read_b128 v[2:5], v0\n\t"                                                                                \
@@ -120,8 +129,8 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     NB_SYM_PRIO_PRE                                                                                              \
     "s_mov_b32 %[cnt], 32\n"                                                                                     \
     "1:\n\t"                                                                                                     \
-    SY_STEP("v2", "v3", "v4", "v5", "ds_read_b128 v[6:9], v0\n\t", GRD)                                          \
-    SY_STEP("v6", "v7", "v8", "v9", "ds_read_b128 v[2:5], v0\n\t", GRD)                                          \
+    SY_STEP("v2", "v3", "v4", "v5", "ds_read_b128 v[6:9], v0\n\t", GRD, POST)                                          \
+    SY_STEP("v6", "v7", "v8", "v9", "ds_read_b128 v[2:5], v0\n\t", GRD, POST)                                          \
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
@@ -169,7 +178,7 @@ __device__ __forceinline__ int sym_group(int g, int wave, int spacing, int G)
 
 // ---- off-diagonal tiles (I < J) ------------------------------------------------------------------------------
 template <int W, bool GUARD>
-__global__ __launch_bounds__(64 * W) void force_sym_kernel(SymArgs a)
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) void force_sym_kernel(SymArgs a)  // <= 96 VGPRs
 {
     constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -178,15 +187,21 @@ __global__ __launch_bounds__(64 * W) void force_sym_kernel(SymArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int2 t = a.tiles[blockIdx.x];
     const int rowbase = t.x * L, colbase = t.y * L;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
     const int row_hi = min(a.row_lo + a.row_count, a.n_total);
     const int S = (a.n_total + L - 1) / L;
+    // the one mass of the row split's / column split's bodies, NaN where they differ (split_mass_kernel): workgroup-uniform
+    const float mass_rows = GUARD ? __builtin_nanf("") : a.split_mass[t.x], mass_cols = GUARD ? mass_rows : a.split_mass[t.y];
+    const bool uniform = !GUARD && mass_rows == mass_rows && mass_cols == mass_cols;
+    const float row_scale = uniform ? mass_cols : 1.f, col_scale = uniform ? mass_rows : 1.f;
 
     for (int c = tid; c < L; c += kSymThreads)
         lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
     __syncthreads();
 
+    auto passes = [&](auto uniform_tag) {  // one copy of the loops per inner-loop variant: no merged live ranges
+    constexpr bool UNIFORM = decltype(uniform_tag)::value;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);  // a local of the lambda: a captured one would live in scratch
     for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
         nb_f4 row[kSymRows];
         float ax[kSymRows], ay[kSymRows], az[kSymRows];
@@ -220,21 +235,28 @@ __global__ __launch_bounds__(64 * W) void force_sym_kernel(SymArgs a)
                 unsigned off = 16u * (unsigned)lane, addr = 0, cnt;
                 const unsigned base = (unsigned)(size_t)lds.stage, mask = 1023u, next_lane = 4u * ((lane + 1) & 63);
                 float eps2 = a.eps2;  // in a VGPR: an SGPR source operand costs an fp32 instruction two extra cycles
-                const float tiny = kGuardMin, pinf = __builtin_inff();
-#define SY_OPERANDS                                                                                                   \
+#define SY_OPERANDS(GUARD_INPUTS)                                                                                     \
                 : "+{v53}"(ax[0]), "+{v54}"(ay[0]), "+{v52}"(az[0]), "+{v57}"(ax[1]), "+{v58}"(ay[1]), "+{v56}"(az[1]),      \
                   "+{v61}"(ax[2]), "+{v62}"(ay[2]), "+{v60}"(az[2]), "+{v65}"(ax[3]), "+{v66}"(ay[3]), "+{v64}"(az[3]),      \
                   "+{v45}"(cx), "+{v68}"(cy), "+{v49}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)                  \
                 : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]), "{v11}"(eps2),     \
-                  "{v69}"(tiny), "{v70}"(pinf), "{v10}"(base), "{v55}"(mask), "{v59}"(next_lane)                                                              \
+                  GUARD_INPUTS "{v10}"(base), "{v55}"(mask), "{v59}"(next_lane)                                              \
                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",      \
                   "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v50", "v51", "scc",    \
                   "vcc", "memory"
-                if (GUARD)
-                    asm volatile(SY_GROUP_LOOP(SY_GUARD) SY_OPERANDS);
-                else
-                    asm volatile(SY_GROUP_LOOP(SY_NOGUARD) SY_OPERANDS);
+#define SY_NO_GUARD_INPUTS
+                if constexpr (GUARD) {
+                    const float tiny = kGuardMin, pinf = __builtin_inff();
+#define SY_GUARD_INPUTS "{v69}"(tiny), "{v70}"(pinf),
+                    asm volatile(SY_GROUP_LOOP(SY_GUARD, SY_POST) SY_OPERANDS(SY_GUARD_INPUTS));
+                } else if constexpr (UNIFORM) {
+                    asm volatile(SY_GROUP_LOOP(SY_NOGUARD, SY_POSTU) SY_OPERANDS(SY_NO_GUARD_INPUTS));
+                } else {
+                    asm volatile(SY_GROUP_LOOP(SY_NOGUARD, SY_POST) SY_OPERANDS(SY_NO_GUARD_INPUTS));
+                }
 #undef SY_OPERANDS
+#undef SY_GUARD_INPUTS
+#undef SY_NO_GUARD_INPUTS
             }
             // after 64 rotations lane l holds column l of the group; force on the column body is -m_row * d * inv3
             lds.sx[cg * 64 + lane] -= cx;
@@ -250,14 +272,58 @@ __global__ __launch_bounds__(64 * W) void force_sym_kernel(SymArgs a)
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             if (r < L && rowbase + r < row_hi)
-                out[rowbase + r - a.row_lo] = make_float4(ax[k], ay[k], az[k], 0.f);
+                out[rowbase + r - a.row_lo] = make_float4(ax[k] * row_scale, ay[k] * row_scale, az[k] * row_scale, 0.f);
         }
     }
+    };
+    if (uniform)
+        passes(std::true_type{});
+    else
+        passes(std::false_type{});
 
     float4 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);  // P_col[R][d-1][.]
     for (int c = tid; c < L; c += kSymThreads)
         if (colbase + c < a.n_total)
-            out[c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
+            out[c] = make_float4(lds.sx[c] * col_scale, lds.sy[c] * col_scale, lds.sz[c] * col_scale, 0.f);
+}
+
+// split_mass[s] = the mass every body of split s has, or NaN when they differ (a ragged last split counts its missing
+// bodies as zero-mass ones).  O(N), launched in front of the tiles: the masses live in the caller's buffer and may
+// change between steps.  Speed only -- a tile takes the same path whatever the sharding, the flag being a function of
+// the data and of the split boundaries.
+__global__ __launch_bounds__(kTile) void split_mass_kernel(const float4 *pos, float *split_mass, int n_total, int split_len,
+                                                           int enabled)
+{
+    __shared__ int differs;
+    if (!enabled) {  // nbody_set_equal_mass_path(ctx, 0): every tile takes the general path
+        if (threadIdx.x == 0)
+            split_mass[blockIdx.x] = __builtin_nanf("");
+        return;
+    }
+    const int base = blockIdx.x * split_len;
+    const float m0 = pos[base].w;  // base < n_total: the grid has ceil(n_total / split_len) workgroups
+    if (threadIdx.x == 0)
+        differs = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int c = threadIdx.x; c < split_len; c += kTile) {
+        const float m = base + c < n_total ? pos[base + c].w : 0.f;
+        bad |= __builtin_bit_cast(unsigned, m) != __builtin_bit_cast(unsigned, m0);
+    }
+    if (bad)
+        differs = 1;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        split_mass[blockIdx.x] = differs || !(fabsf(m0) <= 3.4e38f) ? __builtin_nanf("") : m0;
+}
+
+hipError_t launch_split_mass(const float4 *pos, float *split_mass, int n_total, int split_len, bool enabled, hipStream_t stream)
+{
+    if (n_total <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(split_mass_kernel, dim3((n_total + split_len - 1) / split_len), dim3(kTile), 0, stream, pos, split_mass,
+                       n_total, split_len, enabled ? 1 : 0);
+    return hipGetLastError();
 }
 
 // ---- the compiler-scheduled tile kernel: diagonal tiles, and every tile under per-particle softening ---------------

@@ -264,6 +264,11 @@ class NBodySystem:
     def set_rows_per_lane(self, rpl: int) -> None:
         check(self._lib.nbody_set_rows_per_lane(self._ctx, int(rpl)), self._ctx)
 
+    def set_equal_mass_path(self, on: bool) -> None:
+        """Splits whose bodies all carry one mass leave the mass out of the inner loop (on by default); ``False`` sends
+        every split down the general path (A/B measurement, tests)."""
+        check(self._lib.nbody_set_equal_mass_path(self._ctx, 1 if on else 0), self._ctx)
+
     def device_info(self) -> dict:
         out = (ctypes.c_int64 * 4)()
         name = ctypes.create_string_buffer(128)

@@ -405,6 +405,44 @@ def test_zero_softening_is_safe_for_any_finite_mass(nb, oracle_mod, mode, heavy)
     assert np.array_equal(a[7], a[8])                  # coincident bodies feel the same force, none from each other
 
 
+@pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
+def test_equal_mass_splits_take_a_shorter_inner_loop_with_the_same_answer(nb, oracle_mod, mode):
+    """Splits whose bodies share one mass leave the mass out of the inner loop (nbody_set_equal_mass_path): against the
+    general path the result moves by rounding only, both agree with the fp64 truth, and a body set with a few species
+    in index order (some tiles qualify, some do not -- galaxy_20K.bin's shape) and a ragged tail is handled tile by tile."""
+    n = 9000
+    pos, vel = nb.plummer(n, seed=77)                           # equal masses: every full split qualifies
+    species = pos.copy()
+    species[:2048, 3] *= 17.0                                   # three species in index order, boundaries on and off
+    species[2048:5000, 3] *= 0.25                               # the 256-body split grid
+    for state in (pos, species):
+        acc = {}
+        for on in (True, False):
+            with nb.NBodySystem(n, split_len=256 if mode == "pair_once" else 0) as s:
+                s.set_force_mode(mode)
+                s.set_equal_mass_path(on)
+                s.setParticlesPosition(state)
+                s.setParticlesVelocity(np.zeros_like(vel))
+                s.step(1.0, 1e-2)
+                acc[on] = s.download()[1][:, :3].astype(np.float64)
+        a64 = oracle_mod.accel_f64(state, eps=1e-2)
+        scale = np.linalg.norm(a64)
+        assert np.linalg.norm(acc[True] - a64) / scale < TOL and np.linalg.norm(acc[False] - a64) / scale < TOL
+        assert 0 < np.linalg.norm(acc[True] - acc[False]) / scale < 1e-6        # a different rounding, nothing more
+    # the register blockings of the one-sided kernel stay bit-identical on the short path too
+    if mode == "one_sided":
+        ref = None
+        for rpl in (0, 1, 2, 8, 40, -4):
+            with nb.NBodySystem(n) as s:
+                s.set_rows_per_lane(rpl)
+                s.setParticlesPosition(pos)
+                s.setParticlesVelocity(vel)
+                s.step_n(2, 1e-3, 1e-3)
+                got = s.download()
+            ref = ref or got
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), rpl
+
+
 # ---- diagnostics -----------------------------------------------------------------------------------
 
 def test_energy_and_momentum_match_oracle(nb, oracle_mod):
