@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
     // leaves the loop -- the sums collect d * inv^3 and are multiplied by it once at the end -- 11 fp32 instructions + 1
     // transcendental per interaction instead of 12 + 1.  Decided per split from the data, so every register blocking
     // and every sharding takes the same path for the same split: the variants stay bit-identical among themselves.
-    const float split_mass = (GUARD || PPS) ? __builtin_nanf("") : a.split_mass[split];
+    const float split_mass = GUARD ? __builtin_nanf("") : a.split_mass[split];
     const bool uniform = split_mass == split_mass;
 
     auto tiles = [&](auto uniform_tag) {

@@ -747,7 +747,7 @@ def test_per_particle_softening_in_the_pair_once_mode(nb, oracle_mod, eps):
     assert np.linalg.norm(sym - one) / np.linalg.norm(one) < 1e-6
     zero = pps_accel_mode(nb, pos, np.zeros(n, np.float32), 1e-3, "symmetric", L)
     plain = sym_run(nb, pos, np.zeros_like(pos), 1.0, 1e-3, 1, "symmetric", L)[1][:, :3]
-    assert np.abs(zero - plain).max() / np.abs(plain).max() < 1e-6    # another kernel, the same sums to rounding
+    assert np.abs(zero - plain).max() / np.abs(plain).max() < 3e-6    # another kernel (and m x sum instead of sum of m x term): rounding
     # two contexts sharing the rows (groups 0-3 and 4-7 = splits 0-7 and 8-11), column sums copied by hand
     import torch
     half = 8 * L
