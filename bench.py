@@ -43,7 +43,10 @@ if ROOT not in sys.path:
 FLOP_PER_INTERACTION = 20.0        # SURVEY.md 8d (GPU Gems 3 ch.31 convention)
 # flop the instructions of one pair evaluation really perform (= what rocprofv3's SQ_INSTS_VALU_*_F32 counters add up to)
 FLOP_INSTRUCTIONS = {"one_sided": 19.0,   # 3 sub, 6 fma, 3 mul, 1 rsq
-                     "pair_once": 26.0}   # 3 sub, 9 fma, 4 mul, 1 rsq, for the two interactions of the pair
+                     "pair_once": 26.0,   # 3 sub, 9 fma, 4 mul, 1 rsq, for the two interactions of the pair
+                     # splits whose bodies share one mass (every split of the benchmark's equal-mass sphere): the mass
+                     # multiplies leave the inner loop (nbody_set_equal_mass_path, include/nbody.h)
+                     "one_sided_equal_mass": 18.0, "pair_once_equal_mass": 24.0}
 KERNEL_NAME = {"one_sided": "nbody::force_kernel_r4pk", "pair_once": "nbody::force_sym_kernel"}
 PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md, chip-level parameters: 256 CU x 4 SIMD x 32 lanes x 2 x 2.4 GHz
 
@@ -115,7 +118,7 @@ def executed_pairs(mode, n, split_len, rows_here):
     return (S * (S - 1) / 2 + S) * split_len * split_len * rows_here / n   # off-diagonal tiles + the diagonal ones
 
 
-def roofline(mode, n, split_len, rows_here, steps, tm):
+def roofline(mode, n, split_len, rows_here, steps, tm, equal_mass=True):
     """the fraction is computed from EXECUTED pair evaluations x 20 flop, never from the 2x credit a
     pair-once kernel could claim for the ordered interactions it accounts for.  Both other readings are reported beside
     it under their own names."""
@@ -123,7 +126,7 @@ def roofline(mode, n, split_len, rows_here, steps, tm):
     launches = max(tm["force_launches"], 1)
     executed = executed_pairs(mode, n, split_len, rows_here) * steps
     achieved = FLOP_PER_INTERACTION * executed / force_s / 1e12
-    instr_flop = FLOP_INSTRUCTIONS[mode] * executed / force_s / 1e12
+    instr_flop = FLOP_INSTRUCTIONS[mode + ("_equal_mass" if equal_mass else "")] * executed / force_s / 1e12
     credit = FLOP_PER_INTERACTION * rows_here * n * steps / force_s / 1e12
     traffic = committed_traffic(n, KERNEL_NAME[mode]) if rows_here == n else None
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
@@ -137,18 +140,24 @@ def roofline(mode, n, split_len, rows_here, steps, tm):
             "frac_instruction_flop": instr_flop / PEAK_FP32_VECTOR_TFLOPS,
             "frac_if_credited_per_ordered_interaction": credit / PEAK_FP32_VECTOR_TFLOPS,
             "avg_launch_ms": tm["force_ms"] / launches, "launches": tm["force_launches"],
+            "inner_loop": ("equal-mass splits: the mass leaves the loop, " + ("14 + 1" if mode == "pair_once" else "11 + 1")
+                           if equal_mass else "general masses, " + ("16 + 1" if mode == "pair_once" else "12 + 1")) +
+                          " instructions per pair evaluation",
             "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used.  achieved/frac: executed "
                     "pair evaluations x 20 flop (SURVEY.md 8d).  frac_instruction_flop: the flop the kernel's instructions "
-                    "really perform (one_sided 19 per evaluation; pair_once 26: 3 sub, 9 fma, 4 mul, 1 rsq for TWO "
-                    "interactions).  frac_if_credited_per_ordered_interaction: 20 flop x the ordered interactions the "
-                    "launch accounts for -- NOT a utilisation figure for the pair-once kernel.  Rank 0's kernels."}
+                    "really perform (general masses: one_sided 19 per evaluation, pair_once 26 = 3 sub, 9 fma, 4 mul, 1 rsq "
+                    "for TWO interactions; equal-mass splits: 18 and 24).  frac_if_credited_per_ordered_interaction: 20 flop "
+                    "x the ordered interactions the launch accounts for -- NOT a utilisation figure for the pair-once "
+                    "kernel.  Rank 0's kernels."}
 
 
-def other_mode_leg(nb, mode, n, pos, vel, args):
-    """The force mode that is NOT the headline, on the same state and GPU (N = 1 run only)."""
+def other_mode_leg(nb, mode, n, pos, vel, args, equal_mass_path=True):
+    """Another kernel on the same state and GPU (N = 1 run only): the force mode that is NOT the headline, or the
+    headline mode with the equal-mass inner loop switched off (every split down the general-mass path)."""
     import torch
     s = nb.NBodySystem(n, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0)
     s.set_force_mode(mode)
+    s.set_equal_mass_path(equal_mass_path)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel)
     s.timing(True)
@@ -164,7 +173,7 @@ def other_mode_leg(nb, mode, n, pos, vel, args):
     dt = time.perf_counter() - t0
     tm = s.read_timing()
     out = {"force_mode": mode, "value": float(n) * n * steps / dt, "unit": "interactions/s", "ms_per_step": 1e3 * dt / steps,
-           "steps": steps, "roofline": roofline(mode, n, s.split_len, n, steps, tm)}
+           "steps": steps, "roofline": roofline(mode, n, s.split_len, n, steps, tm, equal_mass_path)}
     s.close()
     return out
 
@@ -365,7 +374,8 @@ def main():
                        "rccl_ranks": rccl_ranks,
                        "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3],
                        "force_mode": mode},
-            "roofline": roofline(mode, n, int(getattr(system, "split_len", 0)), rows_here, args.steps, tm),
+            "roofline": roofline(mode, n, int(getattr(system, "split_len", 0)), rows_here, args.steps, tm,
+                                 equal_mass=bool(np.all(pos[:, 3] == pos[0, 3]))),
             "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
             "update_ms_per_step": tm["update_ms"] / args.steps,
             "diagonal_tiles_ms_per_step": tm.get("aux_ms", 0.0) / args.steps,
@@ -374,6 +384,7 @@ def main():
         }
         if world == 1 and not args.no_extra_legs:
             out["other_force_mode"] = other_mode_leg(nb, "one_sided" if mode == "pair_once" else "pair_once", n, pos, vel, args)
+            out["general_mass_path"] = other_mode_leg(nb, mode, n, pos, vel, args, equal_mass_path=False)
             out["reference_size"] = reference_size_leg(nb)
             both = {mode: out["roofline"], out["other_force_mode"]["force_mode"]: out["other_force_mode"]["roofline"]}
             out["north_star_target"] = {

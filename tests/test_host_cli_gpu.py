@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def run_cli(*args):
     from n_body_problem_amd import build
     exe = build.build_host()
-    res = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr
     return res.stdout
 
@@ -137,3 +137,27 @@ def test_cli_devices_runs_the_library_owned_multi_gpu_step(tmp_path):
             s.step_n(4, 1e-3, 1e-3)
             want_p, want_v = s.download()
         assert step == 4 and np.array_equal(p, want_p[:n]) and np.array_equal(v, want_v[:n]), flags
+
+
+def test_config5_dry_run_two_ranks_on_one_gpu_with_snapshots(tmp_path):
+    """BASELINE configs[4] at reduced length: N = 4 194 304 in the pair-once mode, rows sharded over two ranks (both on
+    cuda:0, peer copies in RCCL's place), 20 steps with the energy at both ends and a snapshot every 10 steps; the run
+    resumed from the step-10 snapshot ends with the bits of the uninterrupted one.  On a node the 1000-step run is the
+    same command with --devices 0,...,7 --steps 1000 --energy-every 100 (RCCL instead of --peer-copy)."""
+    import re
+    from n_body_problem_amd import datasets as ds
+    common = ["--devices", "0,0", "--peer-copy", "--pair-once", "--dt", 1e-3, "--softening", 1e-2]
+    out = run_cli("--plummer", 1 << 22, "--seed", 0x5EED0005, *common, "--steps", 20, "--energy-every", 20, "--dump-every", 10,
+                  "--dump-prefix", tmp_path / "c5", "--final", tmp_path / "straight.nbs")
+    assert "ranks = 2" in out and "rows per rank = 2097152" in out and "split = 2048" in out
+    assert "replicas identical: yes" in out
+    drift = [float(x) for x in re.findall(r"dE/E0 = ([-+0-9.e]+)", out)]
+    assert len(drift) == 1 and abs(drift[0]) < 1e-5, out
+    rate = float(re.search(r"([0-9.e+]+) interactions/s", out).group(1))
+    assert rate > 2e12                                       # two ranks sharing one GPU still run at the one-GPU rate
+    out2 = run_cli("--resume", tmp_path / "c5_000010.nbs", *common, "--steps", 10, "--final", tmp_path / "resumed.nbs")
+    assert "replicas identical: yes" in out2
+    p, v, step, time = ds.load_snapshot(str(tmp_path / "straight.nbs"))
+    p2, v2, step2, time2 = ds.load_snapshot(str(tmp_path / "resumed.nbs"))
+    assert step == step2 == 20 and time == pytest.approx(time2) and p.shape == (1 << 22, 4)
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
