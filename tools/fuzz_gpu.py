@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Seeded random configurations through both force modes on one GPU: pair-once vs one-sided vs the fp64 oracle, and two
-row-sharing contexts (hand-copied exchange) vs one.  python tools/fuzz_gpu.py [cases] [seed]"""
+"""Seeded random configurations through both force modes on one GPU: pair-once vs one-sided vs the fp64 oracle, two
+row-sharing contexts (hand-copied exchange) vs one, and 2-8 shards with the library-owned exchange (nbody_multi_*, peer
+copies) vs one context on the padded system.  Mass patterns: random, equal, a few species in index order (some splits
+take the equal-mass loop, some do not), massless and very heavy bodies.  python tools/fuzz_gpu.py [cases] [seed]"""
 import os
 import sys
 
@@ -59,8 +61,20 @@ def main():
         eps = float(rng.choice([0.0, 1e-3, 1e-2]))
         pos = np.empty((n, 4), np.float32)
         pos[:, :3] = rng.normal(size=(n, 3)).astype(np.float32) * rng.choice([0.1, 1.0, 30.0])
-        pos[:, 3] = rng.uniform(0.0, 2.0, n).astype(np.float32)
-        pos[rng.random(n) < 0.05, 3] = 0.0                       # massless bodies
+        pattern = str(rng.choice(["random", "equal", "species", "heavy"]))
+        if pattern == "equal":
+            pos[:, 3] = np.float32(rng.uniform(0.1, 2.0))
+        elif pattern == "species":                               # contiguous species, boundaries on and off the split grid
+            cuts = np.sort(rng.integers(0, n + 1, size=3))
+            pos[:, 3] = 1.0
+            for c, m in zip(cuts, rng.uniform(0.01, 5.0, 3)):
+                pos[c:, 3] = np.float32(m)
+        else:
+            pos[:, 3] = rng.uniform(0.0, 2.0, n).astype(np.float32)
+            if pattern == "heavy":
+                pos[:, 3] *= np.float32(10.0 ** rng.uniform(3, 12))
+        if pattern != "equal":
+            pos[rng.random(n) < 0.05, 3] = 0.0                   # massless bodies
         if n > 3:                                                # coincident bodies
             k = rng.integers(0, n, size=max(1, n // 50))
             pos[k, :3] = pos[(k + rng.integers(1, n)) % n, :3]
@@ -83,7 +97,32 @@ def main():
             two = accel(pos, eps, mode, L, shards=2)
             if two is not None:
                 assert np.array_equal(two, whole), (case, mode, n, L, eps, "two contexts differ from one")
-        print(f"case {case:3d}: n={n:6d} split_len={L:5d} eps={eps:g} ok (pair vs one {d:.1e})", flush=True)
+        # the library-owned exchange: P shards on this GPU against one context on the same padded system, two steps
+        mode = str(rng.choice(["one_sided", "pair_once"]))
+        world = int(rng.choice([2, 4, 8] if mode == "pair_once" else [2, 3, 4, 5, 8]))
+        exchange, integrator = str(rng.choice(["allgather", "ring"])), str(rng.choice(["kick_drift", "kdk"]))
+        Lm = L if (mode == "pair_once" and L <= 4096) or mode == "one_sided" else 1024
+        vel = (rng.normal(size=(n, 4)) * 0.1).astype(np.float32)
+        from n_body_problem_amd.multi import MultiGpuSystem
+        with MultiGpuSystem(n, devices=[0] * world, force_mode=mode, integrator=integrator, exchange=exchange,
+                            transport="peer_copy", split_len=Lm) as m:
+            m.set_state(pos, vel)
+            m.step_n(2, 1e-3, eps)
+            got = m.download()
+            assert m.replicas_identical()
+            n_padded = m.n_padded
+        pp, vv = np.zeros((n_padded, 4), np.float32), np.zeros((n_padded, 4), np.float32)
+        pp[:n], vv[:n] = pos, vel
+        with nb.NBodySystem(n_padded, split_len=Lm) as s:
+            s.set_force_mode(mode)
+            s.set_integrator(integrator)
+            s.setParticlesPosition(pp)
+            s.setParticlesVelocity(vv)
+            s.step_n(2, 1e-3, eps)
+            want = s.download()
+        assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (case, mode, world, exchange, integrator, n, Lm)
+        print(f"case {case:3d}: n={n:6d} split_len={L:5d} eps={eps:g} masses {pattern:7s} ok (pair vs one {d:.1e}); "
+              f"{world} shards {mode} {exchange} {integrator} = one context", flush=True)
     print("worst relative differences:", {k: float(f"{v:.3e}") for k, v in worst.items()})
 
 
