@@ -89,8 +89,8 @@ float *nbody_velocities_device(nbody_ctx *ctx);
  * dt               : TIME_TICK (kernel.cu:63; the reference uses 0.008).
  * softening        : eps, a length; eps^2 replaces EPSILON (kernel.cu:66).  The reference's VERSION 3
  *                    corresponds to 1e-2 and VERSIONs 1/2 to 1e-3.  0 is allowed: pairs
- *                    at zero distance (the self pair included) then contribute nothing, whatever their
- *                    masses.  0 < softening < NBODY_MIN_SOFTENING is rejected (NBODY_ERR_INVALID): eps^-3 x mass
+ *                    at zero distance (closer than 2.3e-13: the self pair, coincident bodies) then contribute
+ *                    nothing, whatever their masses.  0 < softening < NBODY_MIN_SOFTENING is rejected (NBODY_ERR_INVALID): eps^-3 x mass
  *                    of the self pair would overflow fp32 and poison every sum with 0 x inf.
  * nbody_step returns after the device work is complete (the reference synchronises at kernel.cu:1232,1236);
  * nbody_step_async only enqueues on the context's stream; nbody_sync waits and reports kernel errors. */

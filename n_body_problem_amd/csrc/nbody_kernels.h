@@ -8,11 +8,15 @@ namespace nbody {
 
 constexpr int kTile = 256;  // bodies per LDS tile == threads per workgroup (reference BLOCK_SIZE, kernel.cu:65)
 
-// Zero-distance guard of the eps == 0 kernel variants: a pair whose r^2 is below the smallest normal float (the self
-// pair, coincident bodies) contributes exactly 0 for ANY finite mass -- r^2 is replaced by +inf, so v_rsq_f32 returns 0
-// and every later product is 0 (a clamp of r^2 instead would make m * inv^3 overflow for heavy bodies and 0 * inf = NaN).
-// v_rsq_f32 does not take denormal inputs, hence FLT_MIN rather than 0 as the threshold.  One v_cmp + one v_cndmask.
-constexpr float kGuardMin = 1.17549435e-38f;
+// Zero-distance guard of the eps == 0 kernel variants: a pair whose r^2 is below 2^-84 (closer than 2.3e-13: the self
+// pair, coincident bodies, and bodies that only rounding has moved apart) contributes exactly 0 for ANY finite mass --
+// r^2 is replaced by +inf, so v_rsq_f32 returns 0 and every later product is 0.  A clamp of r^2 instead makes m * inv^3
+// overflow for heavy bodies and 0 * inf = NaN; a threshold at the smallest normal float would still let inv^3 = r^-3
+// overflow (inv up to 1e19) and a ZERO-mass column turn that into 0 * inf = NaN -- which the library's own padding
+// bodies met: zero-mass bodies at one point stay coincident under the one-sided kernels (every row sums its columns in
+// the same order) but drift apart by an ulp under the pair-once tiles (a lane's column order depends on the lane).
+// With r^2 >= 2^-84, inv <= 2^42 and inv^3 <= 2^126 is finite.  One v_cmp + one v_cndmask.
+constexpr float kGuardMin = 0x1p-84f;
 __device__ __forceinline__ float guard_r2(float r2) { return r2 >= kGuardMin ? r2 : __builtin_inff(); }
 
 struct ForceArgs {

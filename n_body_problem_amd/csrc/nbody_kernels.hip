@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 // src1 sit in the same bank (register index mod 4) costs two extra cycles, and the compiled loop has four to five
 // such instructions per interaction.  Allocation (bank = index mod 4):
 //   v0-3 / v4-7   column body {x,y,z,m} (banks 0,1,2,3), double-buffered: the next ds_read_b128 travels in the gap
-//   v8            eps^2 (only ever src2)            v35  FLT_MIN, v53 +inf (GUARD only)          v52  LDS byte address
+//   v8            eps^2 (only ever src2)            v35  2^-84, v53 +inf (GUARD only)          v52  LDS byte address
 //   row k=0..3    x,y,z = v(9+4k), v(10+4k), v(11+4k) (banks 1,2,3)   ax = v(12+4k)   ay,az = v(25+2k), v(26+2k)
 //   temps k       r2/inv/s = v(36+4k) (bank 0)   dx,dy,dz = v(37+4k)..v(39+4k) (banks 1,2,3)   inv^2 = v33/v34
 #define NB_PRE(PX, PY, PZ, X, Y, Z, R, D0, D1, D2, GRD)                                                          \
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
 // the results bit-identical, and 26 -> 14 issued instructions per 2 interactions measured 2 % less time (259.6 -> 254.6 ms
 // per N = 2^20 pass, same box).  force_kernel_r4 above (rows_per_lane = 40) is kept for the comparison.
 // 64-bit operands sit in even-aligned pairs; pair classes ((reg / 2) mod 2) of src0 and src1 differ in every instruction:
-//   v[0:3] / v[4:7]  column body: (x,y) class 0, (z,m) class 1       v[8:9] = (eps^2, -) class 0    v10 = FLT_MIN, v11 = +inf (GUARD)
+//   v[0:3] / v[4:7]  column body: (x,y) class 0, (z,m) class 1       v[8:9] = (eps^2, -) class 0    v10 = 2^-84, v11 = +inf (GUARD)
 //   rows 0,1 / 2,3:  X v[14:15] / v[22:23], Y v[18:19] / v[26:27] (class 1), Z v[12:13] / v[16:17] (class 0)
 //   temps:           DX,DY,DZ v[30:31],v[34:35],v[38:39] / v[42:43],v[46:47],v[50:51] (class 1), R v[20:21] / v[24:25] (class 0),
 //                    Q v[54:55] (class 1)          sums: AX,AY,AZ v[28:29],v[32:33],v[36:37] / v[40:41],v[44:45],v[48:49]
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(kTile) void energy_kernel(const float4 *pos_all, co
             const float4 pj = tile[jj];
             const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
             const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, PPS ? ei2 + etile[jj] : eps2)));
-            const float inv = (j0 + jj != gi && r2 > 0.f) ? __builtin_amdgcn_rsqf(r2) : 0.f;
+            const float inv = (j0 + jj != gi && r2 >= kGuardMin) ? __builtin_amdgcn_rsqf(r2) : 0.f;  // as the forces' guard
             s = __builtin_fmaf(pj.w, inv, s);
         }
         phi += (double)s;

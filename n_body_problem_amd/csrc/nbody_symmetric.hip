@@ -61,7 +61,7 @@ __device__ __forceinline__ float wave_rol1(float v) { return dpp_move<0x134>(v);
 //   shared            inv^2 = v44/v48 (bank 0)   inv^3 = v46/v50 (bank 2)   s_col = v47/v51 (bank 3)
 //   row sums k        az = v(52+4k) (bank 0)  ax = v(53+4k) (bank 1)  ay = v(54+4k) (bank 2)
 //   column sums       cx = v45 (bank 1)  cy = v68 (bank 0)  cz = v49 (bank 1)   (travelling)
-//   v11 = eps^2 (bank 3)   v69 = FLT_MIN, v70 = +inf (GUARD)   v59 = 4 * ((lane + 1) mod 64), the permute's source lane
+//   v11 = eps^2 (bank 3)   v69 = 2^-84, v70 = +inf (GUARD)   v59 = 4 * ((lane + 1) mod 64), the permute's source lane
 //   v0 = LDS byte address of the next read = v10 | (v1 & v55): v1 counts 16 bytes per step from 16*lane, v55 = 1023,
 //   v10 = the wave's 1 KiB-aligned group buffer -- column (lane + s) mod 64 without a second copy of the group.
 typedef float nb_f4 __attribute__((ext_vector_type(4)));
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
     const int S = (a.n_total + L - 1) / L;
     // the one mass of the row split's / column split's bodies, NaN where they differ (split_mass_kernel): workgroup-uniform
     const float mass_rows = GUARD ? __builtin_nanf("") : a.split_mass[t.x], mass_cols = GUARD ? mass_rows : a.split_mass[t.y];
-    const bool uniform = !GUARD && mass_rows == mass_rows && mass_cols == mass_cols;
+    // ... and only when every pass is full: the lanes of a partial last pass (split lengths that are not a multiple of the
+    // rows per pass, e.g. 768 with two waves) carry dummy rows whose zero MASS is what keeps them out of the column sums
+    const bool uniform = !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;
     const float row_scale = uniform ? mass_cols : 1.f, col_scale = uniform ? mass_rows : 1.f;
 
     for (int c = tid; c < L; c += kSymThreads)

@@ -16,6 +16,10 @@ DT, EPS = 1e-3, 1e-3
 
 def one_context(nb, pos, vel, n_padded, split_len, steps, force_mode="one_sided", integrator="kick_drift", eps_pp=None):
     """The same padded body set on ONE context: what P shards must reproduce bit for bit."""
+    return one_context_eps(nb, pos, vel, n_padded, split_len, steps, EPS, force_mode, integrator, eps_pp)
+
+
+def one_context_eps(nb, pos, vel, n_padded, split_len, steps, eps, force_mode="one_sided", integrator="kick_drift", eps_pp=None):
     p = np.zeros((n_padded, 4), dtype=np.float32)
     v = np.zeros((n_padded, 4), dtype=np.float32)
     p[:pos.shape[0]], v[:vel.shape[0]] = pos, vel
@@ -28,9 +32,9 @@ def one_context(nb, pos, vel, n_padded, split_len, steps, force_mode="one_sided"
             s.set_particle_softening(e)
         s.setParticlesPosition(p)
         s.setParticlesVelocity(v)
-        s.step_n(steps, DT, EPS)
+        s.step_n(steps, DT, eps)
         pp, vv = s.download()
-        e = s.energy(EPS)
+        e = s.energy(eps)
         mom = s.momentum()
     n = pos.shape[0]
     return pp[:n], vv[:n], e, mom
@@ -59,6 +63,31 @@ def test_shards_on_one_gpu_reproduce_one_context_bit_for_bit(world, force_mode, 
     want_p, want_v, want_e, want_mom = one_context(nb, pos, vel, n_padded, split_len, steps, force_mode, integrator)
     assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
     assert np.allclose(e, want_e, rtol=1e-9) and np.allclose(mom, want_mom, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("split_len,world", [(2048, 4), (4096, 2)])
+def test_padding_bodies_stay_harmless_without_softening(split_len, world):
+    """softening = 0, pair-once, kick-drift-kick, a body set much smaller than its padding: the zero-mass padding bodies
+    start at one point and the pair-once tiles move them apart by an ulp (a lane's summation order depends on the lane);
+    pairs that close must still contribute nothing -- 0 x inv^3 with an overflowed inv^3 used to be NaN for everybody."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 1316, 3
+    rng = np.random.default_rng(12)
+    pos = np.empty((n, 4), np.float32)
+    pos[:, :3] = rng.normal(size=(n, 3)).astype(np.float32)
+    pos[:, 3] = 1.0
+    vel = (rng.normal(size=(n, 4)) * 0.1).astype(np.float32)
+    with MultiGpuSystem(n, devices=[0] * world, force_mode="pair_once", integrator="kdk", exchange="ring",
+                        transport="peer_copy", split_len=split_len) as m:
+        m.set_state(pos, vel)
+        m.step_n(steps, DT, 0.0)
+        p, v = m.download()
+        e = m.energy(0.0)
+        n_padded, L = m.n_padded, m.split_len
+    assert n_padded == 8 * split_len and np.isfinite(p).all() and np.isfinite(v).all() and np.isfinite(e).all()
+    want_p, want_v, _, _ = one_context_eps(nb, pos, vel, n_padded, L, steps, 0.0, "pair_once", "kdk")
+    assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
 
 
 def test_rccl_leg_with_the_one_rank_this_box_has(oracle_mod):
