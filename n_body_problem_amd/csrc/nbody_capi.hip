@@ -30,7 +30,7 @@ struct nbody_ctx {
     // pair-once mode (nbody_symmetric.hip)
     struct SymTiles { int2 *tiles = nullptr; int n = 0; int2 *diag = nullptr; int n_diag = 0; };
     std::map<std::tuple<int, int, bool>, SymTiles> sym_tiles;  // per column range asked for: its (R, C) tiles
-    float4 *col_partials = nullptr;  // [own splits][n_splits / 2][split_len], see SymArgs
+    float3 *col_partials = nullptr;  // [own splits][n_splits / 2][split_len] 12-byte entries, see SymArgs
     float4 *colparts = nullptr;      // [kSymGroups][n_total] in use: the caller's (nbody_sym_set_colparts) or colparts_own
     float4 *colparts_own = nullptr;
     float4 *sym_acc = nullptr;       // [row_count]: the summed accelerations the update kernels read as one split
@@ -451,7 +451,7 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         c->group_count = c->row_count ? (split_hi + gs - 1) / gs - c->group_lo : 0;
         HIP_TRY(c, hipSetDevice(c->device));
         if (!c->col_partials && c->row_count && c->n_splits > 1 &&
-            hipMalloc((void **)&c->col_partials, sizeof(float4) * (size_t)(split_hi - split_lo) * (size_t)(c->n_splits / 2) *
+            hipMalloc((void **)&c->col_partials, sizeof(float3) * (size_t)(split_hi - split_lo) * (size_t)(c->n_splits / 2) *
                                                      (size_t)c->split_len) != hipSuccess)
             return fail(c, NBODY_ERR_ALLOC, "nbody_set_force_mode: hipMalloc of the column-side partial sums failed (a longer "
                                             "split_len needs less)");
@@ -535,7 +535,7 @@ static int summed_partials(nbody_ctx *c, const char *who, const float4 **partial
             return rc;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, launch_sym_finalize(c->partials, c->colparts, c->sym_acc, (int)c->row_lo, (int)c->row_count, (int)c->n_total,
+    HIP_TRY(c, launch_sym_finalize(reinterpret_cast<const float3 *>(c->partials), c->colparts, c->sym_acc, (int)c->row_lo, (int)c->row_count, (int)c->n_total,
                                    (int)c->split_len, c->n_splits, c->group_splits, c->stream));
     c->sym_reduced = false;
     *partials = c->sym_acc;
@@ -608,8 +608,11 @@ static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
 // The partial-sum array of the current force mode (a mode switch may need a larger one).
 static int ensure_partials(nbody_ctx *c)
 {
-    const size_t slots = c->force_mode == NBODY_FORCE_SYMMETRIC ? (size_t)c->n_splits / 2 + 1 : (size_t)c->n_splits;
-    const size_t entries = slots * (size_t)c->row_count;
+    // one-sided: [n_splits][rows] float4; pair-once: [n_splits / 2 + 1][rows] 12-byte entries (counted in float4 units)
+    const bool sym = c->force_mode == NBODY_FORCE_SYMMETRIC;
+    const size_t slots = sym ? (size_t)c->n_splits / 2 + 1 : (size_t)c->n_splits;
+    const size_t entries = sym ? (slots * (size_t)c->row_count * sizeof(float3) + sizeof(float4) - 1) / sizeof(float4)
+                               : slots * (size_t)c->row_count;
     if (entries <= c->partials_entries)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -700,7 +703,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         }
         SymArgs sa;
         sa.pos = reinterpret_cast<const float4 *>(d_pos);
-        sa.row_partials = c->partials;
+        sa.row_partials = reinterpret_cast<float3 *>(c->partials);
         sa.col_partials = c->col_partials;
         sa.tiles = it->second.tiles;
         sa.n_tiles = it->second.n;

@@ -60,8 +60,10 @@ struct SymArgs {
     const float4 *pos;     // all n_total bodies
     // Both arrays are indexed by the ring distance d = (C - R) mod S of the tile, 0 <= d <= S/2 (0: the diagonal), so
     // they hold exactly the partial sums that exist:
-    float4 *row_partials;  // [S/2 + 1][row_count]: P_row[d][b] = force on own body b (split R) from the bodies of split R + d
-    float4 *col_partials;  // [own splits][S/2][split_len]: P_col[R][d - 1][i] = force on body i of split R + d from own split R
+    // (12-byte entries {x, y, z}: a quarter fewer bytes than float4 for the 2 x n_total^2 / split_len entries a step writes
+    // and the summation kernels read back)
+    float3 *row_partials;  // [S/2 + 1][row_count]: P_row[d][b] = force on own body b (split R) from the bodies of split R + d
+    float3 *col_partials;  // [own splits][S/2][split_len]: P_col[R][d - 1][i] = force on body i of split R + d from own split R
     const int2 *tiles;     // n_tiles pairs (R, C), R an own split, R != C
     int n_tiles;
     const int2 *diag_tiles;  // n_diag pairs (B, B), own splits: every pair inside the split once, both sides
@@ -81,11 +83,11 @@ size_t symmetric_lds_bytes(int split_len);
 
 // colparts[g][c] = sum over the own splits R of group g (ascending, where the tile (R, C(c)) exists) of P_col[R][c],
 // for the own groups [group_lo, group_lo + group_count) and every body c.  colparts is [kSymGroups][n_total].
-hipError_t launch_sym_colparts(const float4 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
+hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
                                int split_lo, int group_splits, int group_lo, int group_count, hipStream_t stream);
 // acc[b] = sum over the groups g (ascending) of ( sum over C in g (ascending, where the tile (B(b), C) exists, and the
 // diagonal C == B(b)) of P_row[C][b]  +  colparts[g][b] ): the same association for any number of ranks.
-hipError_t launch_sym_finalize(const float4 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
+hipError_t launch_sym_finalize(const float3 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
                                int n_total, int split_len, int n_splits, int group_splits, hipStream_t stream);
 
 // Partial accelerations of rows [row_lo,row_lo+row_count) from splits [split_first, split_first+split_count).

@@ -144,7 +144,7 @@ __device__ __forceinline__ int sym_distance(int R, int C, int S)
     return d < 0 ? d + S : d;
 }
 // P_col[R_local][d - 1][0 .. split_len)
-__device__ __forceinline__ float4 *sym_col_slot(float4 *col_partials, int r_local, int d, int S, int L)
+__device__ __forceinline__ float3 *sym_col_slot(float3 *col_partials, int r_local, int d, int S, int L)
 {
     return col_partials + ((size_t)r_local * (size_t)(S / 2) + (size_t)(d - 1)) * (size_t)L;
 }
@@ -269,12 +269,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
         }
         __syncthreads();
 
-        float4 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // row sums: P_row[d][row]
+        float3 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // row sums: P_row[d][row]
 #pragma unroll
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             if (r < L && rowbase + r < row_hi)
-                out[rowbase + r - a.row_lo] = make_float4(ax[k] * row_scale, ay[k] * row_scale, az[k] * row_scale, 0.f);
+                out[rowbase + r - a.row_lo] = make_float3(ax[k] * row_scale, ay[k] * row_scale, az[k] * row_scale);
         }
     }
     };
@@ -283,10 +283,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
     else
         passes(std::false_type{});
 
-    float4 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);  // P_col[R][d-1][.]
+    float3 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);  // P_col[R][d-1][.]
     for (int c = tid; c < L; c += kSymThreads)
         if (colbase + c < a.n_total)
-            out[c] = make_float4(lds.sx[c] * col_scale, lds.sy[c] * col_scale, lds.sz[c] * col_scale, 0.f);
+            out[c] = make_float3(lds.sx[c] * col_scale, lds.sy[c] * col_scale, lds.sz[c] * col_scale);
 }
 
 // split_mass[s] = the mass every body of split s has, or NaN when they differ (a ragged last split counts its missing
@@ -437,21 +437,21 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
                 }
             __syncthreads();
         } else {
-            float4 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // P_row[d][row]
+            float3 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // P_row[d][row]
 #pragma unroll
             for (int k = 0; k < kSymRows; ++k)
                 if (rl[k] >= 0)
-                    out[rowbase + rl[k] - a.row_lo] = make_float4(ax[k], ay[k], az[k], 0.f);
+                    out[rowbase + rl[k] - a.row_lo] = make_float3(ax[k], ay[k], az[k]);
         }
     }
 
     // DIAG: both sides of the split, P_row[0][b]; else the column sums, P_col[R][d-1][.]
-    float4 *out = DIAG ? a.row_partials + (rowbase - a.row_lo)
+    float3 *out = DIAG ? a.row_partials + (rowbase - a.row_lo)
                        : sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);
     const int col_hi = DIAG ? row_hi : a.n_total;  // a diagonal tile's columns are the context's own rows
     for (int c = tid; c < L; c += kSymThreads)
         if (colbase + c < col_hi)
-            out[c] = make_float4(lds.sx[c], lds.sy[c], lds.sz[c], 0.f);
+            out[c] = make_float3(lds.sx[c], lds.sy[c], lds.sz[c]);
 }
 
 // waves per tile workgroup: W x 256 rows per pass must not exceed the split
@@ -537,7 +537,7 @@ hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream)
 // the ranks exchange), and the owner of a body adds, group by group, its row-side terms of the group and the group's
 // column-side sum (sym_finalize_kernel).
 
-__global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float4 *col_partials, float4 *colparts, int n_total,
+__global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float3 *col_partials, float4 *colparts, int n_total,
                                                              int split_len, int n_splits, int split_lo, int group_splits,
                                                              int group_lo)
 {
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float4 *col_p
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int R = r0; R < r1; ++R)
         if (sym_rows_side(R, C, n_splits)) {
-            const float4 v = sym_col_slot(const_cast<float4 *>(col_partials), R - split_lo, sym_distance(R, C, n_splits),
+            const float3 v = sym_col_slot(const_cast<float3 *>(col_partials), R - split_lo, sym_distance(R, C, n_splits),
                                           n_splits, split_len)[off];
             sx += v.x;
             sy += v.y;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float4 *col_p
     colparts[(size_t)g * n_total + c] = make_float4(sx, sy, sz, 0.f);
 }
 
-__global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float4 *row_partials, const float4 *colparts, float4 *acc,
+__global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float3 *row_partials, const float4 *colparts, float4 *acc,
                                                              int row_lo, int row_count, int n_total, int split_len,
                                                              int n_splits, int group_splits)
 {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float4 *row_p
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int C = c0; C < c1; ++C)
             if (C == B || sym_rows_side(B, C, n_splits)) {
-                const float4 v = row_partials[(size_t)sym_distance(B, C, n_splits) * row_count + b];
+                const float3 v = row_partials[(size_t)sym_distance(B, C, n_splits) * row_count + b];
                 sx += v.x;
                 sy += v.y;
                 sz += v.z;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float4 *row_p
     acc[b] = make_float4(ax, ay, az, 0.f);
 }
 
-hipError_t launch_sym_colparts(const float4 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
+hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
                                int split_lo, int group_splits, int group_lo, int group_count, hipStream_t stream)
 {
     if (n_total <= 0 || group_count <= 0)
@@ -596,7 +596,7 @@ hipError_t launch_sym_colparts(const float4 *col_partials, float4 *colparts, int
     return hipGetLastError();
 }
 
-hipError_t launch_sym_finalize(const float4 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
+hipError_t launch_sym_finalize(const float3 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
                                int n_total, int split_len, int n_splits, int group_splits, hipStream_t stream)
 {
     if (row_count <= 0)

@@ -1,0 +1,16 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+python -c 'import __graft_entry__ as g; g.build()' > gpurun_out/r02_s10_build.log 2>&1 || { tail -20 gpurun_out/r02_s10_build.log; exit 1; }
+timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "not config5" > gpurun_out/r02_s10_pytest.log 2>&1
+rc=$?; tail -4 gpurun_out/r02_s10_pytest.log; echo "pytest rc=$rc"
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 600 python tools/fuzz_gpu.py 40 31337 > gpurun_out/r02_s10_fuzz.txt 2>&1; rc=$?; tail -2 gpurun_out/r02_s10_fuzz.txt; echo "fuzz rc=$rc"
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 400 python bench.py --no-cpu-baseline > gpurun_out/r02_s10_bench.json 2> gpurun_out/r02_s10_bench.err
+rc=$?; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r02_s10_bench.json'))
+print({k:d[k] for k in ("value","ms_per_step","update_ms_per_step","diagonal_tiles_ms_per_step")}, d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["general_mass_path"]["ms_per_step"], d["other_force_mode"]["ms_per_step"])
+PY
+echo "bench rc=$rc"
