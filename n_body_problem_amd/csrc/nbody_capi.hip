@@ -969,9 +969,8 @@ int nbody_step_n(nbody_ctx *c, int k, float dt, float softening)
 
 // ---- diagnostics ----------------------------------------------------------------------------
 
-static int reduce_blocks(nbody_ctx *c, int nvals, double *out)
+static int reduce_blocks(nbody_ctx *c, int blocks, int nvals, double *out)
 {
-    const int blocks = energy_blocks((int)c->row_count);
     HIP_TRY(c, hipMemcpyAsync(c->reduce_host.data(), c->reduce_dev, sizeof(double) * (size_t)blocks * nvals,
                               hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -995,7 +994,7 @@ int nbody_energy(nbody_ctx *c, const float *d_pos, const float *d_vel, float sof
                              c->reduce_dev, (int)c->row_lo, (int)c->row_count, (int)c->n_total,
                              softening * softening, c->eps_pp, c->stream));
     double ku[2];
-    int rc = reduce_blocks(c, 2, ku);
+    int rc = reduce_blocks(c, energy_kernel_blocks((int)c->row_count), 2, ku);
     if (rc != NBODY_OK)
         return rc;
     out3[0] = ku[0];
@@ -1014,7 +1013,7 @@ int nbody_momentum(nbody_ctx *c, const float *d_pos, const float *d_vel, double 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_momentum(reinterpret_cast<const float4 *>(d_pos), reinterpret_cast<const float4 *>(d_vel),
                                c->reduce_dev, (int)c->row_lo, (int)c->row_count, c->stream));
-    return reduce_blocks(c, 4, out4);
+    return reduce_blocks(c, energy_blocks((int)c->row_count), 4, out4);
 }
 
 int nbody_device_info(nbody_ctx *c, int64_t *out4, char *name, int name_len)

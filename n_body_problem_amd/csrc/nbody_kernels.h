@@ -115,7 +115,8 @@ hipError_t launch_scatter_mass(float4 *pos_all, const float *masses, int n_total
 // Per-block {kinetic, potential} doubles into block_out[2*gridDim.x]; returns the grid size used.
 hipError_t launch_energy(const float4 *pos_all, const float4 *vel_rows, double *block_out, int row_lo,
                          int row_count, int n_total, float eps2, const float *eps_pp, hipStream_t stream);
-int energy_blocks(int row_count);
+int energy_blocks(int row_count);         // blocks of launch_momentum (one row per lane)
+int energy_kernel_blocks(int row_count);  // blocks of launch_energy (four rows per lane)
 
 // Per-block {px,py,pz,m} doubles into block_out[4*gridDim.x].
 hipError_t launch_momentum(const float4 *pos_all, const float4 *vel_rows, double *block_out, int row_lo,

@@ -669,9 +669,37 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *bloc
     }
 }
 
-// Potential of each row against ALL columns (self pair excluded by index), fp32 pair terms, fp32 sum
-// inside a tile, fp64 across tiles and across rows; kinetic energy of the rows.
-template <bool PPS>
+// Potential of each row against ALL columns (self pair excluded by index), fp32 pair terms, fp32 sum inside a tile,
+// fp64 across tiles and across rows; kinetic energy of the rows.  Four rows per lane feed on each broadcast LDS read;
+// only the (at most four) tiles that hold a workgroup's own rows run the loop with the self-pair test, every other tile
+// the plain one: 7 fp32 instructions + 1 transcendental per pair (the eps = 0 guard adds a compare and a select).
+constexpr int kEnergyRows = 4;
+
+template <bool PPS, bool SELF, bool GUARD>
+__device__ __forceinline__ void energy_tile(const float4 *tile, const float *etile, const float4 (&pi)[kEnergyRows],
+                                            const float (&ei2)[kEnergyRows], const int (&gi)[kEnergyRows], int j0, float eps2,
+                                            double (&phi)[kEnergyRows])
+{
+    float s[kEnergyRows] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int jj = 0; jj < kTile; ++jj) {
+        const float4 pj = tile[jj];
+#pragma unroll
+        for (int k = 0; k < kEnergyRows; ++k) {
+            const float dx = pj.x - pi[k].x, dy = pj.y - pi[k].y, dz = pj.z - pi[k].z;
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, PPS ? ei2[k] + etile[jj] : eps2)));
+            float inv = __builtin_amdgcn_rsqf(GUARD ? guard_r2(r2) : r2);  // guarded: as the forces, pairs closer than 2.3e-13 drop out
+            if (SELF)
+                inv = (j0 + jj != gi[k]) ? inv : 0.f;
+            s[k] = __builtin_fmaf(pj.w, inv, s[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kEnergyRows; ++k)
+        phi[k] += (double)s[k];
+}
+
+template <bool PPS, bool GUARD>
 __global__ __launch_bounds__(kTile) void energy_kernel(const float4 *pos_all, const float4 *vel_rows,
                                                        double *block_out, int row_lo, int row_count, int n_total,
                                                        float eps2, const float *eps_pp)
@@ -679,17 +707,26 @@ __global__ __launch_bounds__(kTile) void energy_kernel(const float4 *pos_all, co
     __shared__ float4 tile[kTile];
     __shared__ float etile[PPS ? kTile : 1];
     const int tid = threadIdx.x;
-    const int r = blockIdx.x * kTile + tid;
-    const bool live = r < row_count;
-    const int gi = row_lo + r;
-    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-    float ei2 = eps2;
-    if (live) {
-        pi = pos_all[gi];
-        if (PPS)
-            ei2 = __builtin_fmaf(eps_pp[gi], eps_pp[gi], eps2);
+    const int row0 = blockIdx.x * (kTile * kEnergyRows);
+    float4 pi[kEnergyRows];
+    float ei2[kEnergyRows];
+    int gi[kEnergyRows];
+    double phi[kEnergyRows];
+#pragma unroll
+    for (int k = 0; k < kEnergyRows; ++k) {
+        const int r = row0 + k * kTile + tid;
+        gi[k] = r < row_count ? row_lo + r : -1;
+        pi[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ei2[k] = eps2;
+        phi[k] = 0.0;
+        if (gi[k] >= 0) {
+            pi[k] = pos_all[gi[k]];
+            if (PPS)
+                ei2[k] = __builtin_fmaf(eps_pp[gi[k]], eps_pp[gi[k]], eps2);
+        }
     }
-    double phi = 0.0;
+    // the tiles that hold this workgroup's rows (row_lo is a multiple of the tile: a split boundary)
+    const int self_lo = row_lo + row0, self_hi = self_lo + kTile * kEnergyRows;
     for (int j0 = 0; j0 < n_total; j0 += kTile) {
         __syncthreads();
         float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -703,25 +740,23 @@ __global__ __launch_bounds__(kTile) void energy_kernel(const float4 *pos_all, co
         if (PPS)
             etile[tid] = et * et;
         __syncthreads();
-        float s = 0.f;
-#pragma unroll 8
-        for (int jj = 0; jj < kTile; ++jj) {
-            const float4 pj = tile[jj];
-            const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, PPS ? ei2 + etile[jj] : eps2)));
-            const float inv = (j0 + jj != gi && r2 >= kGuardMin) ? __builtin_amdgcn_rsqf(r2) : 0.f;  // as the forces' guard
-            s = __builtin_fmaf(pj.w, inv, s);
-        }
-        phi += (double)s;
+        if (j0 + kTile > self_lo && j0 < self_hi)
+            energy_tile<PPS, true, GUARD>(tile, etile, pi, ei2, gi, j0, eps2, phi);
+        else
+            energy_tile<PPS, false, GUARD>(tile, etile, pi, ei2, gi, j0, eps2, phi);
     }
     double v[2] = {0.0, 0.0};
-    if (live) {
-        const float4 w = vel_rows[r];
-        v[0] = 0.5 * (double)pi.w * ((double)w.x * w.x + (double)w.y * w.y + (double)w.z * w.z);
-        v[1] = -0.5 * (double)pi.w * phi;
-    }
+#pragma unroll
+    for (int k = 0; k < kEnergyRows; ++k)
+        if (gi[k] >= 0) {
+            const float4 w = vel_rows[gi[k] - row_lo];
+            v[0] += 0.5 * (double)pi[k].w * ((double)w.x * w.x + (double)w.y * w.y + (double)w.z * w.z);
+            v[1] += -0.5 * (double)pi[k].w * phi[k];
+        }
     block_reduce_store<2>(v, block_out);
 }
+
+int energy_kernel_blocks(int row_count) { return (row_count + kTile * kEnergyRows - 1) / (kTile * kEnergyRows); }
 
 int energy_blocks(int row_count) { return (row_count + kTile - 1) / kTile; }
 
@@ -730,12 +765,17 @@ hipError_t launch_energy(const float4 *pos_all, const float4 *vel_rows, double *
 {
     if (row_count <= 0)
         return hipSuccess;
-    if (eps_pp)
-        hipLaunchKernelGGL(energy_kernel<true>, dim3(energy_blocks(row_count)), dim3(kTile), 0, stream, pos_all, vel_rows,
-                           block_out, row_lo, row_count, n_total, eps2, eps_pp);
+    const dim3 grid(energy_kernel_blocks(row_count)), block(kTile);
+    // a particle may have eps = 0: with per-particle softening the guard stays on when the global eps is 0
+    const bool guard = !(eps2 > 0.f);
+    if (eps_pp && guard)
+        hipLaunchKernelGGL((energy_kernel<true, true>), grid, block, 0, stream, pos_all, vel_rows, block_out, row_lo, row_count, n_total, eps2, eps_pp);
+    else if (eps_pp)
+        hipLaunchKernelGGL((energy_kernel<true, false>), grid, block, 0, stream, pos_all, vel_rows, block_out, row_lo, row_count, n_total, eps2, eps_pp);
+    else if (guard)
+        hipLaunchKernelGGL((energy_kernel<false, true>), grid, block, 0, stream, pos_all, vel_rows, block_out, row_lo, row_count, n_total, eps2, eps_pp);
     else
-        hipLaunchKernelGGL(energy_kernel<false>, dim3(energy_blocks(row_count)), dim3(kTile), 0, stream, pos_all, vel_rows,
-                           block_out, row_lo, row_count, n_total, eps2, eps_pp);
+        hipLaunchKernelGGL((energy_kernel<false, false>), grid, block, 0, stream, pos_all, vel_rows, block_out, row_lo, row_count, n_total, eps2, eps_pp);
     return hipGetLastError();
 }
 
