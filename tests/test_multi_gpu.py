@@ -211,3 +211,50 @@ def test_headline_size_two_shards_on_one_gpu_equal_one_context(oracle_mod, force
     net = (mass[:, None] * acc).sum(0)
     assert np.all(np.abs(net) < 1e-5 * (mass[:, None] * np.abs(acc)).sum(0))      # Newton's third law over 1.1e12 pairs
     assert np.array_equal(p1[:, 3], pos[:, 3]) and np.all(v1[:, 3] == 0)
+
+
+def _one_rank_under_torch_nccl(rank, port, out_path):
+    import torch
+    import torch.distributed as dist
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    from n_body_problem_amd.sharded import sharded_system
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = 8192
+        pos, vel = nb.plummer(n, seed=8)
+        s = sharded_system(n, device=0, force_mode="pair_once", exchange="ring")     # backend nccl -> the library-owned exchange
+        assert isinstance(s, MultiGpuSystem)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        dist.barrier()
+        s.step_n(3, DT, EPS)
+        t = torch.ones(1, device="cuda")
+        dist.all_reduce(t)                                                           # torch's communicator beside the library's
+        p, v = s.download()
+        np.savez(out_path, p=p, v=v, e=s.energy(EPS), rccl_ranks=s.info()["rccl_ranks"], same=s.replicas_identical(),
+                 n_padded=s.n_padded, split_len=s.split_len, t=float(t.item()))
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_exchange_beside_torch_distributed_nccl(tmp_path):
+    """What every rank of `torchrun bench.py --gpus N` does, with the one rank this box has: torch.distributed on the nccl
+    backend (= RCCL) carries the RCCL id and the barriers, the library owns a second communicator in the same process
+    (both bind to the RCCL build PyTorch ships), and the step runs inside the library."""
+    import socket
+    import torch.multiprocessing as mp
+    import n_body_problem_amd as nb
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out = str(tmp_path / "nccl_one_rank.npz")
+    mp.spawn(_one_rank_under_torch_nccl, args=(port, out), nprocs=1, join=True)
+    g = np.load(out)
+    assert int(g["rccl_ranks"]) == 1 and bool(g["same"]) and float(g["t"]) == 1.0
+    pos, vel = nb.plummer(8192, seed=8)
+    want_p, want_v, want_e, _ = one_context(nb, pos, vel, int(g["n_padded"]), int(g["split_len"]), 3, "pair_once")
+    assert np.array_equal(g["p"], want_p) and np.array_equal(g["v"], want_v) and np.allclose(g["e"], want_e, rtol=1e-9)
