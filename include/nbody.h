@@ -173,7 +173,8 @@ enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
  * summation order, so they must not depend on the sharding): 1024 from 204 800 to 2^21 bodies -- the kernel's rows per
  * pass, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles below that (small systems
  * need more, smaller tiles to fill the chip), then 2048 (N = 2^22) and 4096, so that the partial sums
- * (n_total^2 / split_len x 16 B over all contexts) would still fit one GPU. */
+ * (n_total^2 / split_len entries of 12 bytes over all contexts: 12.9 GB at N = 2^20, 103 GB at N = 2^22) would still
+ * fit one GPU. */
 int64_t nbody_pair_once_split_len(int64_t n_total);
 #define NBODY_SYM_GROUPS 8
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);

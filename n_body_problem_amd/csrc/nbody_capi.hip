@@ -40,6 +40,8 @@ struct nbody_ctx {
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream or the caller's)
+    hipStream_t aux_stream = nullptr;  // pair-once mode: the diagonal-tile launch runs here, beside the tile launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float4 *partials = nullptr;    // [n_splits][row_count]  (the reference's gravity_sum_array, kernel.cu:1148);
                                    // pair-once mode: [n_splits / 2 + 1][row_count].  Allocated at the first force call.
     size_t partials_entries = 0;
@@ -114,8 +116,9 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
     // 1024 = the pair-once kernel's rows per pass (4 waves x 64 lanes x 4 rows): shorter splits idle waves, longer ones
     // coarsen the grid (at N = 2^20 one of 8 ranks measured 24.4 ms per step with 1024, 25.8 with 2048, 46.9 with 512;
     // N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms; 4096 leaves 3 workgroups per CU: 441 against 392 ms for one of 8 ranks
-    // at N = 2^22).  The two partial-sum arrays together hold n_total^2 / split_len x 16 B: 17 GB at N = 2^20, and the
-    // length doubles where that would pass 150 GB (137 GB at N = 2^22 with 2048: one GPU can still hold it).
+    // at N = 2^22).  The two partial-sum arrays together hold n_total^2 / split_len entries of 12 bytes: 12.9 GB at
+    // N = 2^20; the length doubles where 16-byte entries (round 1's layout: the rule is kept, split boundaries define
+    // the summation order) would pass 150 GB -- 2048 at N = 2^22: 103 GB, one GPU can still hold it.
     // Below ~200 000 bodies 1024-body tiles are too few to fill 256 CUs x 5 workgroups evenly (N = 131072: 2016 tiles):
     // the splits shrink to n_total / 200, in whole 256-body tiles, and the tile kernel runs with 2 or 1 wave per workgroup.
     const double pairs16 = 16.0 * (double)n_total * (double)n_total;
@@ -182,6 +185,9 @@ int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row
                       std::string(what) + ": " + hipGetErrorString(he));
     };
     guard(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+    guard(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking), "hipStreamCreate");
+    guard(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    guard(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate");
     c->stream = c->own_stream;
     size_t red = (size_t)std::max(1, energy_blocks((int)row_count)) * 4;
     if (rc == NBODY_OK)
@@ -209,6 +215,8 @@ int nbody_destroy(nbody_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->own_stream)
         (void)hipStreamSynchronize(c->own_stream);
+    if (c->aux_stream)
+        (void)hipStreamSynchronize(c->aux_stream);
     for (auto &p : c->ev_force) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : c->ev_update) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : c->ev_aux) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -227,6 +235,9 @@ int nbody_destroy(nbody_ctx *c)
     if (c->sym_acc) (void)hipFree(c->sym_acc);
     if (c->split_mass) (void)hipFree(c->split_mass);
     if (c->acc) (void)hipFree(c->acc);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return NBODY_OK;
@@ -351,8 +362,10 @@ struct TimedLaunch {
     EventPairs *list;
     double *ms;
     int64_t *count;
+    hipStream_t stream;
     hipEvent_t a = nullptr, b = nullptr;
-    TimedLaunch(nbody_ctx *ctx, EventPairs *l, double *total_ms, int64_t *launches) : c(ctx), list(l), ms(total_ms), count(launches)
+    TimedLaunch(nbody_ctx *ctx, EventPairs *l, double *total_ms, int64_t *launches, hipStream_t on = nullptr, bool other = false)
+        : c(ctx), list(l), ms(total_ms), count(launches), stream(other ? on : ctx->stream)
     {
         if (!c->timing)
             return;
@@ -367,12 +380,12 @@ struct TimedLaunch {
             a = b = nullptr;
             return;
         }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, stream);
     }
     ~TimedLaunch()
     {
         if (a && b) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, stream);
             list->emplace_back(a, b);
         }
     }
@@ -718,14 +731,20 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.split_mass = c->split_mass;
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, launch_split_mass(sa.pos, c->split_mass, sa.n_total, L, c->equal_mass_path, c->stream));
+        // the diagonal tiles (pairs inside one split; their own slot of the row-side array) on the auxiliary stream, beside
+        // the tile launch: 0.56 ms at N = 2^20 that no longer stands between the tiles and the summation
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        {
+            TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches, c->aux_stream, true);  // reported separately
+            HIP_TRY(c, launch_forces_symmetric_diag(sa, c->aux_stream));
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
         {
             TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone: rocprofv3's time for it
             HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
         }
-        {
-            TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches);  // the diagonal tiles, reported separately
-            HIP_TRY(c, launch_forces_symmetric_diag(sa, c->stream));
-        }
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         for (int s = 0; s < c->n_splits; ++s)
             if ((s >= first && s < first + count) != complement)
                 c->split_done[(size_t)s] = 1;
