@@ -16,11 +16,21 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(paths):
+    """Of the files several profiler runs left in one directory (named <pid>_*.csv), those of the latest run."""
+    paths = list(paths)
+    if not paths:
+        return []
+    latest = max(paths, key=os.path.getmtime)
+    pid = os.path.basename(latest).split("_")[0]
+    return [f for f in paths if os.path.basename(f).split("_")[0] == pid and os.path.dirname(f) == os.path.dirname(latest)]
+
+
 def main(tag, rnd, n, kern="force_kernel", mode=""):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    stats = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{rnd}_kernel_stats{'_' + mode if mode else ''}.csv"))
     out = {"n": n, "round": rnd, "kernel": "nbody::" + kern, "source": f"tools/profile.sh {tag} (rocprofv3, separate --pmc passes)"}
@@ -28,14 +38,14 @@ def main(tag, rnd, n, kern="force_kernel", mode=""):
     durations = []
     vgpr = None
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for f in newest(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))):
             for r in csv.DictReader(open(f)):
                 if kern in r["Kernel_Name"]:
                     counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     vgpr = r.get("VGPR_Count")
                     out["kernel_name"] = r["Kernel_Name"]
                     out["lds_block_size"] = int(r["LDS_Block_Size"])
-    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+    for f in newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 durations.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
