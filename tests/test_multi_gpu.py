@@ -90,6 +90,28 @@ def test_padding_bodies_stay_harmless_without_softening(split_len, world):
     assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
 
 
+@pytest.mark.parametrize("n", [0, 1, 7, 300])
+def test_empty_and_tiny_body_sets_through_the_multi_object(n, oracle_mod):
+    """Edge sizes (the reference's loaders can return an empty vector, kernel.cu:195-199): nothing but padding on most
+    ranks, every call still valid, the real bodies' result the oracle's."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    pos, vel = nb.uniform_cube(n, seed=3, random_masses=True, speed=0.2)
+    for mode, world in (("one_sided", 3), ("pair_once", 8)):
+        with MultiGpuSystem(n, devices=[0] * world, force_mode=mode, transport="peer_copy", exchange="ring") as m:
+            assert m.n_padded % world == 0 and m.n_padded >= max(n, 1)
+            m.set_state(pos, vel)
+            m.step_n(2, DT, EPS)
+            p, v = m.download()
+            e, mom = m.energy(EPS), m.momentum()
+            assert m.replicas_identical()
+        assert p.shape == (n, 4) and v.shape == (n, 4) and np.isfinite(e).all() and np.isfinite(mom).all()
+        if n:
+            pr, vr = oracle_mod.step_f32(pos, vel, DT, EPS, nsteps=2)
+            assert rel_state_error(p, pr) < 1e-6 and np.abs(v[:, :3] - vr[:, :3]).max() <= 1e-6 * max(np.abs(vr[:, :3]).max(), 1e-30) + 1e-9
+            assert np.array_equal(p[:, 3], pos[:, 3]) and np.array_equal(v[:, 3], vel[:, 3])
+
+
 def test_rccl_leg_with_the_one_rank_this_box_has(oracle_mod):
     """ncclCommInitAll / ncclCommInitRank, the in-place ncclAllGather (a no-op copy with one rank is never issued: world 1
     skips the exchange, so the communicator is exercised by the diagnostics' collectives) and the error poll."""
