@@ -99,6 +99,13 @@ int nbody_step(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw
 int nbody_step_async(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, const float *d_masses,
                      float dt, float softening);
 int nbody_step_n(nbody_ctx *ctx, int k, float dt, float softening); /* k steps on the owned buffers, one sync */
+/* The same on caller-owned device buffers.  Where the loop is launch-bound -- measured: the pair-once mode (seven launches
+ * on two streams per step) up to 32 768 bodies; the three launches of a one-sided step are faster enqueued eagerly at every
+ * size -- ONE step is captured from the stream into a HIP graph after an eager first step and replayed k - 1 times: the
+ * same kernels, arguments and order, hence the same bits.  nbody_set_graph_replay: -1 automatic (that rule), 0 never,
+ * 1 always. */
+int nbody_step_n_on(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, int k, float dt, float softening);
+int nbody_set_graph_replay(nbody_ctx *ctx, int mode);
 int nbody_sync(nbody_ctx *ctx);
 
 /* ---- the two halves of a step, for callers that interleave an exchange (multi-GPU) ----

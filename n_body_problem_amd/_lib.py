@@ -45,6 +45,8 @@ _PROTOTYPES = {
     "nbody_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float]),
     "nbody_step_async": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float]),
     "nbody_step_n": (c_int, [c_void_p, c_int, c_float, c_float]),
+    "nbody_step_n_on": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float]),
+    "nbody_set_graph_replay": (c_int, [c_void_p, c_int]),
     "nbody_sync": (c_int, [c_void_p]),
     "nbody_forces": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "nbody_forces_complement": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),

@@ -40,8 +40,23 @@ struct nbody_ctx {
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream or the caller's)
+    // nbody_step_n on small systems: one step captured into a HIP graph and replayed (the inner loop is launch-bound)
+    hipGraphExec_t step_graph = nullptr;
+    struct GraphKey {
+        const void *pos = nullptr, *vel = nullptr, *eps_pp = nullptr, *stream = nullptr;
+        float dt = 0.f, softening = 0.f;
+        int force_mode = -1, integrator = -1, rows_per_lane = 0;
+        bool equal_mass = false;
+        bool operator==(const GraphKey &o) const
+        {
+            return pos == o.pos && vel == o.vel && eps_pp == o.eps_pp && stream == o.stream && dt == o.dt &&
+                   softening == o.softening && force_mode == o.force_mode && integrator == o.integrator &&
+                   rows_per_lane == o.rows_per_lane && equal_mass == o.equal_mass;
+        }
+    } graph_key;
+    int graph_replay = -1;  // -1: automatic (systems of at most kGraphAutoBodies bodies), 0: off, 1: on
     hipStream_t aux_stream = nullptr;  // pair-once mode: the diagonal-tile launch runs here, beside the tile launch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_graph_in = nullptr, ev_graph_out = nullptr;
     float4 *partials = nullptr;    // [n_splits][row_count]  (the reference's gravity_sum_array, kernel.cu:1148);
                                    // pair-once mode: [n_splits / 2 + 1][row_count].  Allocated at the first force call.
     size_t partials_entries = 0;
@@ -188,6 +203,8 @@ int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row
     guard(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking), "hipStreamCreate");
     guard(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     guard(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate");
+    guard(hipEventCreateWithFlags(&c->ev_graph_in, hipEventDisableTiming), "hipEventCreate");
+    guard(hipEventCreateWithFlags(&c->ev_graph_out, hipEventDisableTiming), "hipEventCreate");
     c->stream = c->own_stream;
     size_t red = (size_t)std::max(1, energy_blocks((int)row_count)) * 4;
     if (rc == NBODY_OK)
@@ -235,8 +252,11 @@ int nbody_destroy(nbody_ctx *c)
     if (c->sym_acc) (void)hipFree(c->sym_acc);
     if (c->split_mass) (void)hipFree(c->split_mass);
     if (c->acc) (void)hipFree(c->acc);
+    if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_graph_in) (void)hipEventDestroy(c->ev_graph_in);
+    if (c->ev_graph_out) (void)hipEventDestroy(c->ev_graph_out);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -512,6 +532,7 @@ int nbody_sym_groups(const nbody_ctx *c, int64_t *group_lo, int64_t *group_count
 }
 
 static int all_splits_done(nbody_ctx *c, const char *who);
+extern "C" int nbody_step_n_on(nbody_ctx *c, float *d_pos, float *d_vel, int k, float dt, float softening);
 
 int nbody_sym_reduce(nbody_ctx *c)
 {
@@ -971,15 +992,96 @@ int nbody_step(nbody_ctx *c, float *d_pos, float *d_vel, const float *d_masses, 
     return rc == NBODY_OK ? nbody_sync(c) : rc;
 }
 
+// Measured (tools/graph_ab.py, profiles/r02_graph_replay_ab.txt): a graph launch costs ~10 us more than three kernels
+// enqueued back to back, so the one-sided step (flags, forces, update) is FASTER eager at every size (N = 256: 29 against
+// 40 us per step; N = 20 225: 143 against 153); the pair-once step is seven launches on two streams with events between
+// them, and there the replay wins up to a few ten thousand bodies (N = 4096: 96 against 114 us; N = 20 225: 169 against
+// 190; N = 65 536: 801 against 788).  Automatic = pair-once mode and at most this many bodies.
+constexpr int64_t kGraphAutoBodies = 32768;
+
+int nbody_set_graph_replay(nbody_ctx *c, int mode)
+{
+    if (!c || mode < -1 || mode > 1)
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_graph_replay: expected -1 (automatic), 0 or 1");
+    c->graph_replay = mode;
+    return NBODY_OK;
+}
+
 int nbody_step_n(nbody_ctx *c, int k, float dt, float softening)
 {
     if (!c || k < 0)
         return fail(c, NBODY_ERR_INVALID, "nbody_step_n: bad argument");
     if ((c->n_total && !c->pos) || (c->row_count && !c->vel))
         return fail(c, NBODY_ERR_STATE, "nbody_step_n: call nbody_set_positions and nbody_set_velocities first");
-    for (int s = 0; s < k; ++s) {
-        int rc = nbody_step_async(c, reinterpret_cast<float *>(c->pos), reinterpret_cast<float *>(c->vel), nullptr, dt,
-                                  softening);
+    return nbody_step_n_on(c, reinterpret_cast<float *>(c->pos), reinterpret_cast<float *>(c->vel), k, dt, softening);
+}
+
+// k steps on the given buffers, one synchronisation at the end.  The first step runs eagerly (it may allocate: partial
+// sums, tile lists, and in the kick-drift-kick mode it computes the initial accelerations); from the second on, when the
+// system is small, ONE step is captured from the stream into a HIP graph and the graph is launched k - 1 times: the same
+// kernels with the same arguments in the same order, so the same bits, without the per-launch host work and with the
+// dependencies resolved on the device.
+int nbody_step_n_on(nbody_ctx *c, float *d_pos, float *d_vel, int k, float dt, float softening)
+{
+    if (!c || k < 0)
+        return fail(c, NBODY_ERR_INVALID, "nbody_step_n: bad argument");
+    const bool whole = c->row_lo == 0 && c->row_count == c->n_total;
+    const bool want = c->graph_replay == 1 || (c->graph_replay == -1 && c->force_mode == NBODY_FORCE_SYMMETRIC &&
+                                               c->n_total <= kGraphAutoBodies);
+    const bool use_graph = want && whole && !c->timing && k >= 3 && c->n_total > 0;
+    int s = 0;
+    if (use_graph) {
+        int rc = nbody_step_async(c, d_pos, d_vel, nullptr, dt, softening);  // eager: allocations, caches, first forces
+        if (rc != NBODY_OK)
+            return rc;
+        ++s;
+        nbody_ctx::GraphKey key;
+        key.pos = d_pos; key.vel = d_vel; key.eps_pp = c->eps_pp; key.stream = nullptr;
+        key.dt = dt; key.softening = softening;
+        key.force_mode = c->force_mode; key.integrator = c->integrator; key.rows_per_lane = c->rows_per_lane;
+        key.equal_mass = c->equal_mass_path;
+        HIP_TRY(c, hipSetDevice(c->device));
+        // The graph lives on the context's own stream (the caller's may be the legacy default stream, which cannot be
+        // captured); events order it behind the eager step and the caller's stream behind it.
+        hipStream_t user = c->stream;
+        if (user != c->own_stream) {
+            HIP_TRY(c, hipEventRecord(c->ev_graph_in, user));
+            HIP_TRY(c, hipStreamWaitEvent(c->own_stream, c->ev_graph_in, 0));
+        }
+        if (!c->step_graph || !(c->graph_key == key)) {
+            if (c->step_graph) {
+                (void)hipGraphExecDestroy(c->step_graph);
+                c->step_graph = nullptr;
+            }
+            hipGraph_t graph = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeThreadLocal));
+            c->stream = c->own_stream;
+            rc = nbody_step_async(c, d_pos, d_vel, nullptr, dt, softening);
+            c->stream = user;
+            hipError_t e = hipStreamEndCapture(c->own_stream, &graph);
+            if (rc != NBODY_OK || e != hipSuccess || !graph) {
+                if (graph)
+                    (void)hipGraphDestroy(graph);
+                return rc != NBODY_OK ? rc : fail(c, NBODY_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            }
+            e = hipGraphInstantiate(&c->step_graph, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                c->step_graph = nullptr;
+                return fail(c, NBODY_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            }
+            c->graph_key = key;
+        }
+        for (; s < k; ++s)
+            HIP_TRY(c, hipGraphLaunch(c->step_graph, c->own_stream));
+        if (user != c->own_stream) {
+            HIP_TRY(c, hipEventRecord(c->ev_graph_out, c->own_stream));
+            HIP_TRY(c, hipStreamWaitEvent(user, c->ev_graph_out, 0));
+        }
+        return nbody_sync(c);
+    }
+    for (; s < k; ++s) {
+        int rc = nbody_step_async(c, d_pos, d_vel, nullptr, dt, softening);
         if (rc != NBODY_OK)
             return rc;
     }

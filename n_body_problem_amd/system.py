@@ -140,12 +140,15 @@ class NBodySystem:
               self._ctx)
 
     def step_n(self, k: int, dt: float = TIME_TICK, softening: float = SOFTENING_VERSION3) -> None:
-        """``k`` steps enqueued back to back, one synchronisation at the end."""
+        """``k`` steps enqueued back to back, one synchronisation at the end (``nbody_step_n_on``: small systems replay a
+        captured HIP graph of one step, see :meth:`set_graph_replay`)."""
         self._use_current_stream()
-        for _ in range(int(k)):
-            check(self._lib.nbody_step_async(self._ctx, _ptr(self.positions), _ptr(self.velocities), None, float(dt),
-                                             float(softening)), self._ctx)
-        self.sync()
+        check(self._lib.nbody_step_n_on(self._ctx, _ptr(self.positions), _ptr(self.velocities), int(k), float(dt),
+                                        float(softening)), self._ctx)
+
+    def set_graph_replay(self, mode: int) -> None:
+        """-1: automatic (pair-once mode up to 32 768 bodies, where the replay measured faster), 0: never, 1: always."""
+        check(self._lib.nbody_set_graph_replay(self._ctx, int(mode)), self._ctx)
 
     def forces(self, col_lo: int, col_count: int, softening: float, positions=None) -> None:
         """Partial accelerations of this context's rows from columns ``[col_lo, col_lo+col_count)`` (async)."""

@@ -449,6 +449,32 @@ def test_equal_mass_splits_take_a_shorter_inner_loop_with_the_same_answer(nb, or
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), rpl
 
 
+@pytest.mark.parametrize("mode,integrator", [("one_sided", "kick_drift"), ("pair_once", "kick_drift"), ("pair_once", "kdk"),
+                                             ("one_sided", "kdk")])
+def test_graph_replay_of_a_step_gives_the_same_bits(nb, mode, integrator):
+    """nbody_step_n on small systems replays ONE captured step as a HIP graph: the same kernels in the same order, so the
+    state must equal the eagerly launched loop bit for bit -- also when the masses change between two calls (the
+    equal-mass flags are recomputed inside the graph) and when the loop is called again (the graph is reused)."""
+    n = 6000
+    pos, vel = nb.plummer(n, seed=3)
+    out = {}
+    for replay in (1, 0):
+        with nb.NBodySystem(n, split_len=256 if mode == "pair_once" else 0) as s:
+            s.set_force_mode(mode)
+            s.set_integrator(integrator)
+            s.set_graph_replay(replay)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            s.step_n(7, 1e-3, 1e-2)
+            s.step_n(5, 1e-3, 1e-2)                       # the cached graph again
+            s.positions[: n // 2, 3] *= 3.0               # half the bodies three times as heavy: other inner loops
+            s.invalidate_forces()
+            s.step_n(4, 1e-3, 1e-2)
+            s.step_n(3, 2e-3, 1e-2)                       # another dt: a new graph
+            out[replay] = s.download()
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+
+
 # ---- diagnostics -----------------------------------------------------------------------------------
 
 def test_energy_and_momentum_match_oracle(nb, oracle_mod):

@@ -1,5 +1,5 @@
 import sys, time, ctypes
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
 import n_body_problem_amd as nb
 from n_body_problem_amd import _lib
