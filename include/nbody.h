@@ -281,7 +281,10 @@ int nbody_multi_step_n(nbody_multi *m, int k, float dt, float softening);
 int nbody_multi_step_async(nbody_multi *m, float dt, float softening);
 int nbody_multi_sync(nbody_multi *m);
 
-/* Diagnostics of the WHOLE system, the same values on every process.  replica_checksums: out2 = {smallest, largest}
+/* In the one-rank-per-process model every call from nbody_multi_set_state to nbody_multi_replica_checksums is
+ * COLLECTIVE: all ranks make the same calls in the same order (the steps exchange rows, download gathers the
+ * velocities, the diagnostics reduce over the ranks).
+ * Diagnostics of the WHOLE system, the same values on every process.  replica_checksums: out2 = {smallest, largest}
  * checksum of the position replicas over all ranks -- equal when every rank holds the same bits. */
 int nbody_multi_energy(nbody_multi *m, float softening, double *out3);
 int nbody_multi_momentum(nbody_multi *m, double *out4);
