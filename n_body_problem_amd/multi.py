@@ -87,12 +87,12 @@ class MultiGpuSystem:
             devs = list(devices if devices is not None else [0])
             arr = (ctypes.c_int * len(devs))(*devs)
             _check(self._lib.nbody_multi_create(ctypes.byref(m), ctypes.byref(cfg), arr, len(devs)))
-            self.rank = 0
+            self.rank, self._devices = 0, devs
         else:
             dev = int((devices or [0])[0])
             ident = ctypes.create_string_buffer(_unique_id, UNIQUE_ID_BYTES)
             _check(self._lib.nbody_multi_create_rank(ctypes.byref(m), ctypes.byref(cfg), dev, int(_rank), int(_world_size), ident))
-            self.rank = int(_rank)
+            self.rank, self._devices = int(_rank), [dev]
         self._m = m
         info = self.info()
         self.n_padded, self.chunk, self.split_len = info["n_padded"], info["rows_per_rank"], info["split_len"]
@@ -149,6 +149,28 @@ class MultiGpuSystem:
         view.num_bodies, view.split_len = self.n_padded, self.split_len
         view.close = lambda: None  # borrowed
         return view
+
+    def positions_tensor(self, local_index: int = 0):
+        """Local rank ``local_index``'s position replica as a zero-copy ``(n_padded, 4)`` float32 torch tensor on its
+        device -- the mapped-pointer analogue of kernel.cu:1226 (a renderer reads it between steps).  Borrowed: valid
+        until :meth:`close`; read it after :meth:`sync` (a step leaves the exchange of the updated rows in flight)."""
+        return self._device_tensor(self._lib.nbody_multi_positions_device(self._m, int(local_index)), self.n_padded,
+                                   int(local_index))
+
+    def velocities_tensor(self, local_index: int = 0):
+        """Local rank ``local_index``'s own velocity rows, ``(rows_per_rank, 4)``, zero-copy."""
+        return self._device_tensor(self._lib.nbody_multi_velocities_device(self._m, int(local_index)), self.chunk,
+                                   int(local_index))
+
+    def _device_tensor(self, ptr, rows: int, local_index: int):
+        import torch
+        if not ptr or not rows:
+            raise NBodyError(_lib.NBODY_ERR_STATE, "no such buffer")
+
+        class _Borrowed:  # the CUDA array interface is how torch adopts foreign device memory without a copy
+            __cuda_array_interface__ = {"shape": (int(rows), 4), "typestr": "<f4", "data": (int(ptr), False), "version": 3,
+                                        "strides": None}
+        return torch.as_tensor(_Borrowed(), device=torch.device("cuda", self._devices[local_index]))
 
     def set_timeout(self, seconds: float) -> None:
         _check(self._lib.nbody_multi_set_timeout(self._m, float(seconds)), self._m)

@@ -168,10 +168,14 @@ def test_particle_softening_and_timing_views_on_shards():
             m.shard(i).timing(True)
         m.step_n(steps, DT, EPS)
         p, v = m.download()
+        views = [m.positions_tensor(i).cpu().numpy() for i in range(2)]      # the mapped-pointer analogue, per local rank
+        vviews = [m.velocities_tensor(i).cpu().numpy() for i in range(2)]
         tm = [m.shard(i).read_timing() for i in range(2)]
         info = m.kernels.device_info()
         n_padded, split_len = m.n_padded, m.split_len
     assert "gfx950" in info["name"]
+    assert np.array_equal(views[0][:n], p) and np.array_equal(views[1][:n], p)                 # zero-copy replica views
+    assert np.array_equal(np.concatenate(vviews)[:n], v)
     for t in tm:                        # own chunk + complement per step, one update per step
         assert t["force_launches"] == 2 * steps and t["update_launches"] == steps and t["force_ms"] > 0
     want_p, want_v, _, _ = one_context(nb, pos, vel, n_padded, split_len, steps, eps_pp=eps_pp)
