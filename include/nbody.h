@@ -236,7 +236,8 @@ int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);
  * the local ranks fused with ncclGroupStart/End); nbody_multi_create_rank -- one rank per process (the launch model of
  * torchrun / mpirun): rank 0 calls nbody_multi_unique_id and the caller hands the 128 bytes to every rank by any
  * channel it has.  Failure detection: RCCL's asynchronous error state is polled after every step and inside every
- * wait; a wait longer than the timeout (default 1800 s, NBODY_EXCHANGE_TIMEOUT_S or nbody_multi_set_timeout) aborts the
+ * wait; nbody_multi_step_n keeps the host at most four steps ahead of the device, so no wait covers more than four steps,
+ * and a wait longer than the timeout (default 600 s, NBODY_EXCHANGE_TIMEOUT_S or nbody_multi_set_timeout) aborts the
  * communicators and returns NBODY_ERR_DEVICE instead of hanging on a dead peer. */
 typedef struct nbody_multi nbody_multi;
 #define NBODY_UNIQUE_ID_BYTES 128

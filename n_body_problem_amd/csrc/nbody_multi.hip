@@ -54,10 +54,13 @@ struct Rank {
     ncclComm_t nccl = nullptr;
     hipEvent_t ev_start = nullptr, ev_side = nullptr;
     std::vector<hipEvent_t> ev_hop;  // ring: hop h has been sent by this rank (PEER) / has landed at this rank (RCCL)
+    std::vector<hipEvent_t> ev_step; // nbody_multi_step_n: the end of the last kStepsInFlight steps on the compute stream
     unsigned long long *scratch = nullptr;  // 4 x 8 bytes on the device (checksum, all-reduce staging)
 };
 
 }  // namespace
+
+constexpr int kStepsInFlight = 4;  // nbody_multi_step_n lets the host run this many steps ahead of the device
 
 struct nbody_multi {
     nbody_multi_config cfg{};
@@ -68,7 +71,7 @@ struct nbody_multi {
     bool exchange_in_flight = false;  // the position exchange of the last update has been issued and not yet consumed
     bool kdk_ready = false;
     bool have_state = false;
-    double timeout_s = 1800.0;
+    double timeout_s = 600.0;  // per wait: a wait never covers more than kStepsInFlight steps
     float *gather_vel = nullptr;  // multi-process download: all velocities, on the first local device
     std::string err;
 };
@@ -222,6 +225,8 @@ static int setup_ranks(nbody_multi *m)
                               &m->ch_col.done[i]})
             MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
         int rc = make_events(m, r.ev_hop, (size_t)m->world);
+        if (rc == NBODY_OK)
+            rc = make_events(m, r.ev_step, (size_t)kStepsInFlight);
         if (rc != NBODY_OK)
             return rc;
         MHIP(m, hipStreamSynchronize(r.compute));
@@ -385,6 +390,9 @@ extern "C" int nbody_multi_destroy(nbody_multi *m)
         for (hipEvent_t e : r.ev_hop)
             if (e)
                 (void)hipEventDestroy(e);
+        for (hipEvent_t e : r.ev_step)
+            if (e)
+                (void)hipEventDestroy(e);
         for (Channel *c : {&m->ch_pos, &m->ch_col}) {
             if (i < c->ready.size() && c->ready[i]) (void)hipEventDestroy(c->ready[i]);
             if (i < c->done.size() && c->done[i]) (void)hipEventDestroy(c->done[i]);
@@ -402,6 +410,8 @@ extern "C" int nbody_multi_destroy(nbody_multi *m)
 }
 
 // ---- waiting, with failure detection ---------------------------------------------------------------------------------
+
+static int timed_out(nbody_multi *m, double waited);
 
 static int poll_async_errors(nbody_multi *m)
 {
@@ -443,16 +453,8 @@ static int wait_all(nbody_multi *m)
             if (rc != NBODY_OK)
                 return rc;
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (waited > m->timeout_s) {
-                for (Rank &r : m->ranks)
-                    if (r.nccl) {
-                        (void)ncclCommAbort(r.nccl);
-                        r.nccl = nullptr;
-                    }
-                return mfail(m, NBODY_ERR_DEVICE, "timed out after " + std::to_string((int)waited) +
-                                                      " s waiting for the step (a peer rank is gone or stuck); the RCCL "
-                                                      "communicators were aborted");
-            }
+            if (waited > m->timeout_s)
+                return timed_out(m, waited);
         }
         std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 20 : 200));
     }
@@ -461,6 +463,46 @@ static int wait_all(nbody_multi *m)
         MHIP(m, hipGetLastError());
     }
     return poll_async_errors(m);
+}
+
+static int timed_out(nbody_multi *m, double waited)
+{
+    for (Rank &r : m->ranks)
+        if (r.nccl) {
+            (void)ncclCommAbort(r.nccl);
+            r.nccl = nullptr;
+        }
+    return mfail(m, NBODY_ERR_DEVICE, "timed out after " + std::to_string((int)waited) +
+                                          " s waiting for the step (a peer rank is gone or stuck); the RCCL "
+                                          "communicators were aborted");
+}
+
+// Waits until slot `slot` of every local rank's step events has fired: the host never runs more than kStepsInFlight
+// steps ahead, so every wait is short and a dead peer is noticed within the timeout whatever the length of the run.
+static int wait_step(nbody_multi *m, int slot)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (Rank &r : m->ranks) {
+        MHIP(m, hipSetDevice(r.device));
+        for (;;) {
+            hipError_t e = hipEventQuery(r.ev_step[(size_t)slot]);
+            if (e == hipSuccess)
+                break;
+            if (e != hipErrorNotReady)
+                return mfail(m, NBODY_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(e));
+            if ((++spins & 63u) == 0) {
+                int rc = poll_async_errors(m);
+                if (rc != NBODY_OK)
+                    return rc;
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > m->timeout_s)
+                    return timed_out(m, waited);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 20 : 200));
+        }
+    }
+    return NBODY_OK;
 }
 
 extern "C" int nbody_multi_sync(nbody_multi *m)
@@ -771,9 +813,16 @@ extern "C" int nbody_multi_step_n(nbody_multi *m, int k, float dt, float softeni
     if (!m || k < 0)
         return mfail(m, NBODY_ERR_INVALID, "nbody_multi_step_n: bad argument");
     for (int s = 0; s < k; ++s) {
-        int rc = step_async(m, dt, softening);
+        const int slot = s % kStepsInFlight;
+        int rc = s >= kStepsInFlight ? wait_step(m, slot) : NBODY_OK;  // step s - kStepsInFlight has finished
+        if (rc == NBODY_OK)
+            rc = step_async(m, dt, softening);
         if (rc != NBODY_OK)
             return rc;
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            MHIP(m, hipEventRecord(r.ev_step[(size_t)slot], r.compute));
+        }
     }
     return settle(m);
 }
