@@ -750,6 +750,10 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.eps2 = softening * softening;
         sa.eps_pp = c->eps_pp;
         sa.split_mass = c->split_mass;
+        // equal-mass tiles run the packed two-columns-per-step loop (163 against 170 ms per N = 2^20 pass); NBODY_SYM_PACKED=0
+        // keeps the one-column loop for A/B measurement
+        static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 1;
+        sa.packed = packed_env;
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, launch_split_mass(sa.pos, c->split_mass, sa.n_total, L, c->equal_mass_path, c->stream));
         // the diagonal tiles (pairs inside one split; their own slot of the row-side array) on the auxiliary stream, beside

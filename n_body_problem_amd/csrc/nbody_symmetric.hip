@@ -39,7 +39,7 @@ namespace nbody {
 // A tile's workgroup has W wave64 (W x 256 rows per pass): 4 for splits of 1024 bodies or more, fewer for the shorter
 // splits of small systems, so that no wave is left without rows (sym_waves()).
 constexpr int kSymRows = 4;  // rows per lane
-constexpr int kSymStageFloatsPerWave = 64 * 4;  // one 64-body group (1 KiB, 1 KiB-aligned) per wave
+constexpr int kSymStageFloatsPerWave = 512;  // per wave 2 KiB, 1 KiB-aligned: one 64-body group as float4[64] (or SoA, below)
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v)
@@ -65,6 +65,7 @@ __device__ __forceinline__ float wave_rol1(float v) { return dpp_move<0x134>(v);
 //   v0 = LDS byte address of the next read = v10 | (v1 & v55): v1 counts 16 bytes per step from 16*lane, v55 = 1023,
 //   v10 = the wave's 1 KiB-aligned group buffer -- column (lane + s) mod 64 without a second copy of the group.
 typedef float nb_f4 __attribute__((ext_vector_type(4)));
+typedef float nb_f2 __attribute__((ext_vector_type(2)));
 #define SY_PRE(PX, PY, PZ, X, Y, Z, D0, D1, D2, R, GRD)                                                          \
     "v_sub_f32_e32 " D0 ", " PX ", " X "\n\tv_sub_f32_e32 " D1 ", " PY ", " Y "\n\tv_sub_f32_e32 " D2 ", " PZ ", " Z "\n\t" \
     "v_fma_f32 " R ", " D0 ", " D0 ", v11\n\tv_fmac_f32_e32 " R ", " D1 ", " D1 "\n\tv_fmac_f32_e32 " R ", " D2 ", " D2 "\n\t" GRD(R)
@@ -137,6 +138,75 @@ typedef float nb_f4 __attribute__((ext_vector_type(4)));
     "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
+// ---- equal-mass tiles, packed: TWO columns per step, one packed fp32 instruction for both (SymArgs::packed, the default) ----
+// Lane l meets columns (l + s) and (l + s + 32) mod 64 at step s = 0..31, the pair sharing every v_pk_{add,mul,fma}_f32:
+// 7 packed instructions + 1 transcendental per pair evaluation instead of 14 + 1 (the cycles are the same, 4 per packed
+// instruction; what halves is the number of instructions issued -- the kernel sits on the power limit).  The group is
+// staged as three arrays x[96], y[96], z[96] (the first 32 columns repeated behind the 64, so column + 32 needs no wrap)
+// and read with ds_read2_b32; both columns' sums travel one lane per step (six permutes for eight pairs); the row sums are
+// kept per column of the pair and added when the pass ends.  Two batches of 2 rows x 2 columns per step keep the batch of
+// four v_rsq_f32 of the other loops.  64-bit operands in even pairs; pair classes ((reg / 2) mod 2) of src0 and src1 differ:
+//   column pair  PX = v[2:3] (1)  PZ = v[4:5] (0)  PY = v[6:7] (1)        v[8:9] = (eps^2, -)
+//   rows         v[12:27] as above: (x, y) pairs class 0, (z, m) pairs class 1
+//   temps A / B  R = v[28:29] / v[32:33] (0)   DX, DY, DZ = v[30:31], v[34:35], v[38:39] / v[42:43], v[46:47], v[50:51] (1)
+//   Q = v[54:55] (1)     column sums CX, CY, CZ = v[36:37], v[40:41], v[44:45]      row sums v[56:79]: row k, component c at
+//   v[56 + 6k + 2c : 57 + 6k + 2c]          v0 / v1 / v10 / v52 / v53: address, offset, base, mask (255), permute source
+#define S2_NEG " neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define S2_PRE(RXY, RZM, DX, DY, DZ, R)                                                                          \
+    "v_pk_add_f32 " DX ", v[2:3], " RXY " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                      \
+    "v_pk_add_f32 " DY ", v[6:7], " RXY " op_sel:[0,1] op_sel_hi:[1,1]" S2_NEG                                      \
+    "v_pk_add_f32 " DZ ", v[4:5], " RZM " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                      \
+    "v_pk_fma_f32 " R ", " DX ", " DX ", v[8:9] op_sel_hi:[1,1,0]\n\t"                                              \
+    "v_pk_fma_f32 " R ", " DY ", " DY ", " R "\n\t"                                                                  \
+    "v_pk_fma_f32 " R ", " DZ ", " DZ ", " R "\n\t"
+#define S2_POST(AX, AY, AZ, DX, DY, DZ, R)                                                                       \
+    "v_pk_mul_f32 v[54:55], " R ", " R "\n\tv_pk_mul_f32 " R ", " R ", v[54:55]\n\t"                                 \
+    "v_pk_fma_f32 " AX ", " DX ", " R ", " AX "\n\tv_pk_fma_f32 " AY ", " DY ", " R ", " AY "\n\t"                     \
+    "v_pk_fma_f32 " AZ ", " DZ ", " R ", " AZ "\n\t"                                                                 \
+    "v_pk_fma_f32 v[36:37], " DX ", " R ", v[36:37]\n\tv_pk_fma_f32 v[40:41], " DY ", " R ", v[40:41]\n\t"             \
+    "v_pk_fma_f32 v[44:45], " DZ ", " R ", v[44:45]\n\t"
+#define S2_ROTATE                                                                                                \
+    "ds_bpermute_b32 v36, v53, v36\n\tds_bpermute_b32 v37, v53, v37\n\tds_bpermute_b32 v40, v53, v40\n\t"            \
+    "ds_bpermute_b32 v41, v53, v41\n\tds_bpermute_b32 v44, v53, v44\n\tds_bpermute_b32 v45, v53, v45\n\t"
+#define S2_READ                                                                                                  \
+    "ds_read2_b32 v[2:3], v0 offset1:32\n\tds_read2_b32 v[6:7], v0 offset0:96 offset1:128\n\t"                       \
+    "ds_read2_b32 v[4:5], v0 offset0:192 offset1:224\n\t"
+#define S2_GROUP_LOOP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    "v_and_or_b32 v0, v1, v52, v10\n\t"                                                                          \
+    S2_READ                                                                                                      \
+    S2_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 32\n"                                                                                     \
+    "1:\n\t"                                                                                                     \
+    "v_add_u32_e32 v1, 4, v1\n\t"                                                                                \
+    "v_and_or_b32 v0, v1, v52, v10\n\t"                                                                          \
+    "s_waitcnt lgkmcnt(6)\n\t" /* the column pair has arrived; the six permutes behind it may be in flight */    \
+    S2_PRE("v[12:13]", "v[14:15]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
+    S2_PRE("v[16:17]", "v[18:19]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
+    "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
+    NB_SYM_GAP                                                                                                   \
+    "s_waitcnt lgkmcnt(0)\n\t" /* the column sums have arrived from the next lane */                             \
+    NB_SYM_PRIO_POST                                                                                             \
+    S2_POST("v[56:57]", "v[58:59]", "v[60:61]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                  \
+    S2_POST("v[62:63]", "v[64:65]", "v[66:67]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                  \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S2_PRE("v[20:21]", "v[22:23]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
+    S2_PRE("v[24:25]", "v[26:27]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
+    S2_READ /* the next step's column pair: the current one has been consumed by the four PRE blocks */          \
+    "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
+    NB_SYM_GAP                                                                                                   \
+    NB_SYM_PRIO_POST                                                                                             \
+    S2_POST("v[68:69]", "v[70:71]", "v[72:73]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                  \
+    S2_POST("v[74:75]", "v[76:77]", "v[78:79]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                  \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S2_ROTATE                                                                                                    \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"
+
 // ring distance of the tile (R, C): its slot in the partial-sum arrays
 __device__ __forceinline__ int sym_distance(int R, int C, int S)
 {
@@ -158,7 +228,7 @@ template <int W>
 __device__ __forceinline__ SymLds sym_lds(float *smem, int L)
 {
     SymLds s;
-    s.stage = reinterpret_cast<float4 *>(smem) + (threadIdx.x >> 6) * 64;
+    s.stage = reinterpret_cast<float4 *>(smem) + (threadIdx.x >> 6) * (kSymStageFloatsPerWave / 4);
     s.sx = smem + W * kSymStageFloatsPerWave;
     s.sy = s.sx + L;
     s.sz = s.sy + L;
@@ -201,8 +271,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
         lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
     __syncthreads();
 
-    auto passes = [&](auto uniform_tag) {  // one copy of the loops per inner-loop variant: no merged live ranges
-    constexpr bool UNIFORM = decltype(uniform_tag)::value;
+    auto passes = [&](auto variant_tag) {  // one copy of the loops per inner-loop variant: no merged live ranges
+    constexpr int VARIANT = decltype(variant_tag)::value;  // 0 general masses, 1 equal-mass tile, 2 equal-mass tile, packed
+    constexpr bool UNIFORM = VARIANT == 1;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);  // a local of the lambda: a captured one would live in scratch
     for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
         nb_f4 row[kSymRows];
@@ -223,14 +294,57 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
             if (gc < a.n_total)
                 cnext = a.pos[gc];
         }
+        nb_f2 ra[kSymRows][3];  // VARIANT 2: row sums per column of the pair
+#pragma unroll
+        for (int k = 0; k < kSymRows; ++k)
+            ra[k][0] = ra[k][1] = ra[k][2] = nb_f2{0.f, 0.f};
         for (int g = 0; g < G; ++g) {
             const int cg = sym_group(g, wave, spacing, G);
-            lds.stage[lane] = cnext;
+            if constexpr (VARIANT == 2) {  // the group as x[96], y[96], z[96]: columns 0..31 repeated behind the 64
+                float *st = reinterpret_cast<float *>(lds.stage);
+                st[lane] = cnext.x;
+                st[96 + lane] = cnext.y;
+                st[192 + lane] = cnext.z;
+                if (lane < 32) {
+                    st[64 + lane] = cnext.x;
+                    st[160 + lane] = cnext.y;
+                    st[256 + lane] = cnext.z;
+                }
+            } else {
+                lds.stage[lane] = cnext;
+            }
             if (g + 1 < G) {
                 const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + lane;
                 cnext = zero4;
                 if (gc < a.n_total)
                     cnext = a.pos[gc];
+            }
+            if constexpr (VARIANT == 2) {
+                nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
+                unsigned off = 4u * (unsigned)lane, addr = 0, cnt;
+                const unsigned base = (unsigned)(size_t)lds.stage, mask = 255u, next_lane = 4u * ((lane + 1) & 63);
+                const nb_f2 epsv = {a.eps2, 0.f};
+                asm volatile(S2_GROUP_LOOP
+                             : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
+                               "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
+                               "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                             : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
+                               "{v[8:9]}"(epsv), "{v10}"(base), "{v52}"(mask), "{v53}"(next_lane)
+                             : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
+                               "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory");
+                // after 32 steps and rotations the lane holds the first-half sum of column lane + 32 and the second-half
+                // sum of column lane: two LDS updates in program order (a column's two halves come from different lanes)
+                const int ca = cg * 64 + ((lane + 32) & 63), cb = cg * 64 + lane;
+                lds.sx[ca] -= cx.x;
+                lds.sy[ca] -= cy.x;
+                lds.sz[ca] -= cz.x;
+                lds.sx[cb] -= cx.y;
+                lds.sy[cb] -= cy.y;
+                lds.sz[cb] -= cz.y;
+                if ((g + 1) % spacing == 0)
+                    __syncthreads();
+                continue;
             }
             float cx = 0.f, cy = 0.f, cz = 0.f;  // accumulators of column (lane + s) mod 64, travelling
             {
@@ -274,14 +388,19 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             if (r < L && rowbase + r < row_hi)
-                out[rowbase + r - a.row_lo] = make_float3(ax[k] * row_scale, ay[k] * row_scale, az[k] * row_scale);
+                out[rowbase + r - a.row_lo] = VARIANT == 2 ? make_float3((ra[k][0].x + ra[k][0].y) * row_scale,
+                                                                          (ra[k][1].x + ra[k][1].y) * row_scale,
+                                                                          (ra[k][2].x + ra[k][2].y) * row_scale)
+                                                           : make_float3(ax[k] * row_scale, ay[k] * row_scale, az[k] * row_scale);
         }
     }
     };
-    if (uniform)
-        passes(std::true_type{});
+    if (uniform && a.packed)
+        passes(std::integral_constant<int, 2>{});
+    else if (uniform)
+        passes(std::integral_constant<int, 1>{});
     else
-        passes(std::false_type{});
+        passes(std::integral_constant<int, 0>{});
 
     float3 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);  // P_col[R][d-1][.]
     for (int c = tid; c < L; c += kSymThreads)
