@@ -142,7 +142,8 @@ def roofline(mode, n, split_len, rows_here, steps, tm, equal_mass=True):
             "avg_launch_ms": tm["force_ms"] / launches, "launches": tm["force_launches"],
             "inner_loop": ("equal-mass splits: the mass leaves the loop, " + ("14 + 1" if mode == "pair_once" else "11 + 1")
                            if equal_mass else "general masses, " + ("16 + 1" if mode == "pair_once" else "12 + 1")) +
-                          " instructions per pair evaluation",
+                          " fp32 operations per pair evaluation, issued as packed instructions (two " +
+                          ("columns" if mode == "pair_once" else "rows") + " each)",
             "note": "fp32 vector (VALU) peak = fp32 MFMA dense peak = 157.3 TFLOP/s; no MFMA used.  achieved/frac: executed "
                     "pair evaluations x 20 flop (SURVEY.md 8d).  frac_instruction_flop: the flop the kernel's instructions "
                     "really perform (general masses: one_sided 19 per evaluation, pair_once 26 = 3 sub, 9 fma, 4 mul, 1 rsq "

@@ -207,6 +207,58 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
+// ---- the same two-columns-per-step loop for tiles with arbitrary masses: 8 packed instructions + 1 transcendental per pair
+// (one-column loop: 16 + 1).  The group's masses are staged as a fourth array m[96] behind x, y, z and read at the END of
+// a step (the positions are consumed by the PRE blocks, the masses by the POST blocks of both batches).
+//   v9 = the wave's stage base   PM = v[10:11] (1) the pair's masses   v48 = address of the masses   S = v[80:81] (0) m_col * inv^3
+#define S3_POST(RZM, AX, AY, AZ, DX, DY, DZ, R)                                                                  \
+    "v_pk_mul_f32 v[54:55], " R ", " R "\n\tv_pk_mul_f32 " R ", " R ", v[54:55]\n\t"                                 \
+    "v_pk_mul_f32 v[80:81], v[10:11], " R "\n\t"                                                                   \
+    "v_pk_mul_f32 " R ", " R ", " RZM " op_sel:[0,1] op_sel_hi:[1,1]\n\t"                                           \
+    "v_pk_fma_f32 " AX ", " DX ", v[80:81], " AX "\n\tv_pk_fma_f32 " AY ", " DY ", v[80:81], " AY "\n\t"             \
+    "v_pk_fma_f32 " AZ ", " DZ ", v[80:81], " AZ "\n\t"                                                              \
+    "v_pk_fma_f32 v[36:37], " DX ", " R ", v[36:37]\n\tv_pk_fma_f32 v[40:41], " DY ", " R ", v[40:41]\n\t"             \
+    "v_pk_fma_f32 v[44:45], " DZ ", " R ", v[44:45]\n\t"
+#define S3_GROUP_LOOP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    "v_and_or_b32 v0, v1, v52, v9\n\t"                                                                           \
+    "v_add_u32_e32 v48, 1152, v0\n\t"                                                                            \
+    S2_READ                                                                                                      \
+    "ds_read2_b32 v[10:11], v48 offset1:32\n\t"                                                                  \
+    S2_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 32\n"                                                                                     \
+    "1:\n\t"                                                                                                     \
+    "v_add_u32_e32 v1, 4, v1\n\t"                                                                                \
+    "v_and_or_b32 v0, v1, v52, v9\n\t"                                                                           \
+    "v_add_u32_e32 v48, 1152, v0\n\t"                                                                            \
+    "s_waitcnt lgkmcnt(7)\n\t" /* the positions of the column pair have arrived (masses and permutes may be in flight) */ \
+    S2_PRE("v[12:13]", "v[14:15]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
+    S2_PRE("v[16:17]", "v[18:19]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
+    "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
+    NB_SYM_GAP                                                                                                   \
+    "s_waitcnt lgkmcnt(0)\n\t" /* the masses and the column sums have arrived */                                 \
+    NB_SYM_PRIO_POST                                                                                             \
+    S3_POST("v[14:15]", "v[56:57]", "v[58:59]", "v[60:61]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")      \
+    S3_POST("v[18:19]", "v[62:63]", "v[64:65]", "v[66:67]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S2_PRE("v[20:21]", "v[22:23]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
+    S2_PRE("v[24:25]", "v[26:27]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
+    S2_READ /* the next step's positions */                                                                      \
+    "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
+    NB_SYM_GAP                                                                                                   \
+    NB_SYM_PRIO_POST                                                                                             \
+    S3_POST("v[22:23]", "v[68:69]", "v[70:71]", "v[72:73]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")      \
+    S3_POST("v[26:27]", "v[74:75]", "v[76:77]", "v[78:79]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "ds_read2_b32 v[10:11], v48 offset1:32\n\t" /* the next step's masses */                                     \
+    S2_ROTATE                                                                                                    \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"
+
 // ring distance of the tile (R, C): its slot in the partial-sum arrays
 __device__ __forceinline__ int sym_distance(int R, int C, int S)
 {
@@ -272,7 +324,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
     __syncthreads();
 
     auto passes = [&](auto variant_tag) {  // one copy of the loops per inner-loop variant: no merged live ranges
-    constexpr int VARIANT = decltype(variant_tag)::value;  // 0 general masses, 1 equal-mass tile, 2 equal-mass tile, packed
+    // 0 general masses, 1 equal-mass tile (one column per step); packed, two columns per step: 2 equal-mass tile, 3 general masses
+    constexpr int VARIANT = decltype(variant_tag)::value;
+    constexpr bool PACKED = VARIANT >= 2;
     constexpr bool UNIFORM = VARIANT == 1;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);  // a local of the lambda: a captured one would live in scratch
     for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
@@ -300,15 +354,19 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
             ra[k][0] = ra[k][1] = ra[k][2] = nb_f2{0.f, 0.f};
         for (int g = 0; g < G; ++g) {
             const int cg = sym_group(g, wave, spacing, G);
-            if constexpr (VARIANT == 2) {  // the group as x[96], y[96], z[96]: columns 0..31 repeated behind the 64
+            if constexpr (PACKED) {  // the group as x[96], y[96], z[96] (, m[96]): columns 0..31 repeated behind the 64
                 float *st = reinterpret_cast<float *>(lds.stage);
                 st[lane] = cnext.x;
                 st[96 + lane] = cnext.y;
                 st[192 + lane] = cnext.z;
+                if (VARIANT == 3)
+                    st[288 + lane] = cnext.w;
                 if (lane < 32) {
                     st[64 + lane] = cnext.x;
                     st[160 + lane] = cnext.y;
                     st[256 + lane] = cnext.z;
+                    if (VARIANT == 3)
+                        st[352 + lane] = cnext.w;
                 }
             } else {
                 lds.stage[lane] = cnext;
@@ -318,6 +376,32 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
                 cnext = zero4;
                 if (gc < a.n_total)
                     cnext = a.pos[gc];
+            }
+            if constexpr (VARIANT == 3) {
+                nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
+                unsigned off = 4u * (unsigned)lane, addr = 0, cnt;
+                const unsigned base = (unsigned)(size_t)lds.stage, mask = 255u, next_lane = 4u * ((lane + 1) & 63);
+                const float eps2 = a.eps2;
+                asm volatile(S3_GROUP_LOOP
+                             : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
+                               "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
+                               "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                             : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
+                               "{v8}"(eps2), "{v9}"(base), "{v52}"(mask), "{v53}"(next_lane)
+                             : "v2", "v3", "v4", "v5", "v6", "v7", "v10", "v11", "v28", "v29", "v30", "v31", "v32", "v33", "v34",
+                               "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v48", "v50", "v51", "v54", "v55", "v80", "v81",
+                               "scc", "memory");
+                const int ca = cg * 64 + ((lane + 32) & 63), cb = cg * 64 + lane;  // as in the equal-mass loop below
+                lds.sx[ca] -= cx.x;
+                lds.sy[ca] -= cy.x;
+                lds.sz[ca] -= cz.x;
+                lds.sx[cb] -= cx.y;
+                lds.sy[cb] -= cy.y;
+                lds.sz[cb] -= cz.y;
+                if ((g + 1) % spacing == 0)
+                    __syncthreads();
+                continue;
             }
             if constexpr (VARIANT == 2) {
                 nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
@@ -388,7 +472,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             if (r < L && rowbase + r < row_hi)
-                out[rowbase + r - a.row_lo] = VARIANT == 2 ? make_float3((ra[k][0].x + ra[k][0].y) * row_scale,
+                out[rowbase + r - a.row_lo] = PACKED ? make_float3((ra[k][0].x + ra[k][0].y) * row_scale,
                                                                           (ra[k][1].x + ra[k][1].y) * row_scale,
                                                                           (ra[k][2].x + ra[k][2].y) * row_scale)
                                                            : make_float3(ax[k] * row_scale, ay[k] * row_scale, az[k] * row_scale);
@@ -399,6 +483,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
         passes(std::integral_constant<int, 2>{});
     else if (uniform)
         passes(std::integral_constant<int, 1>{});
+    else if (!GUARD && a.packed)
+        passes(std::integral_constant<int, 3>{});
     else
         passes(std::integral_constant<int, 0>{});
 

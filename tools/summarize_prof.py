@@ -77,7 +77,8 @@ def main(tag, rnd, n, kern="force_kernel", mode=""):
         # wave64 instructions x 64 lanes; an FMA is 2 flop, everything else 1 (v_sub_f32 is counted with the adds)
         # force_kernel_r4pk does all its adds, multiplies and FMAs as v_pk_*_f32: the counters see one instruction for two
         # lanes' worth (7.1 VALU instructions per interaction instead of 13.1), so each counts double
-        pk = 2.0 if "r4pk" in kern else 1.0
+        # (round 2: so do the pair-once tiles, two columns per packed instruction)
+        pk = 2.0 if ("r4pk" in kern or "force_sym_kernel" in kern) else 1.0
         flop = 64.0 * (pk * (mean["SQ_INSTS_VALU_ADD_F32"] + mean["SQ_INSTS_VALU_MUL_F32"] + 2.0 * mean["SQ_INSTS_VALU_FMA_F32"]) +
                        mean["SQ_INSTS_VALU_TRANS_F32"])
         out["rocprof_flop_per_launch"] = flop
