@@ -156,9 +156,11 @@ int nbody_momentum(nbody_ctx *ctx, const float *d_positions_xyzm, const float *d
  * With timing on, every force / update launch is bracketed by events.  nbody_timing_read synchronises,
  * returns the accumulated milliseconds and launch counts since the last read, and resets them. */
 int nbody_timing_enable(nbody_ctx *ctx, int on);
-/* out6 = {force_ms, force launches, update_ms, update launches, diagonal-tile ms, diagonal-tile launches}: the totals are
- * SUMS of per-launch durations (launches that overlap on two streams each count in full), not wall time; the pair-once
- * mode's diagonal-tile kernel is kept apart from the dominant tile kernel.  Waits for every recorded launch. */
+/* out6 = {force_ms, force launches, update_ms, update launches, auxiliary ms, auxiliary launches}: the totals are SUMS of
+ * per-launch durations (launches that overlap on two streams each count in full), not wall time.  force = the dominant
+ * force kernel; update = what runs behind the force pass (summation, update, kicks); auxiliary = what the pair-once mode
+ * runs on its second stream BESIDE the tile launches (the diagonal tiles, the early summation of the finished row
+ * groups) -- stretched by the sharing, hidden in wall time.  Waits for every recorded launch. */
 int nbody_timing_read_ex(nbody_ctx *ctx, double *out6);
 int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches, double *update_ms,
                       int64_t *update_launches);
@@ -215,6 +217,13 @@ int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
  * sharding, column ranges, GPU count); against the general path the results differ by rounding (m x sum instead of
  * sum of m x term).  0 switches it off: every split takes the general path (A/B measurement, tests). */
 int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
+
+/* Early summation (pair-once mode, one context that owns every row; on by default).  The partial sums are added in row
+ * groups (NBODY_SYM_GROUPS), so the tiles are launched in two parts -- every group but the last, then the last -- and while
+ * the last group's tiles run, an auxiliary stream already forms the sums of the finished groups: of the summation only the
+ * last group's share (an eighth) and the combination stay behind the force pass.  The result does not change by a bit
+ * (the association is by groups either way); 0 restores the single launch followed by the whole summation. */
+int nbody_set_early_summation(nbody_ctx *ctx, int on);
 
 /* Device facts for the roofline: out = {compute units, max clock MHz, wavefront size, LDS bytes per CU}. */
 int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);

@@ -21,6 +21,7 @@ struct nbody_ctx {
     int n_splits = 0;
     int rows_per_lane = 0;  // 0 = pick per launch
     bool equal_mass_path = true;  // splits whose bodies share one mass take the inner loop without mass multiplies
+    bool early_summation = true;  // pair-once mode, one context: sums of the finished row groups beside the last group's tiles
     int force_mode = NBODY_FORCE_ONE_SIDED;
     int integrator = NBODY_INTEGRATOR_KICK_DRIFT;
     float4 *acc = nullptr;      // kick-drift-kick mode: accelerations of the own rows at the current positions
@@ -28,12 +29,17 @@ struct nbody_ctx {
     const float *eps_pp = nullptr;  // per-particle softening lengths in use, n_total floats (borrowed or eps_own), or NULL
     float *eps_own = nullptr;       // the copy nbody_upload_particle_softening made
     // pair-once mode (nbody_symmetric.hip)
-    struct SymTiles { int2 *tiles = nullptr; int n = 0; int2 *diag = nullptr; int n_diag = 0; };
+    // tiles: first n_early (those whose row split lies in every group but the last: their sums are formed on the auxiliary
+    // stream while the remaining n - n_early run), then the rest; n_early = 0: one launch
+    struct SymTiles { int2 *tiles = nullptr; int n = 0, n_early = 0; int2 *diag = nullptr; int n_diag = 0; };
     std::map<std::tuple<int, int, bool>, SymTiles> sym_tiles;  // per column range asked for: its (R, C) tiles
     float3 *col_partials = nullptr;  // [own splits][n_splits / 2][split_len] 12-byte entries, see SymArgs
     float4 *colparts = nullptr;      // [kSymGroups][n_total] in use: the caller's (nbody_sym_set_colparts) or colparts_own
     float4 *colparts_own = nullptr;
     float4 *sym_acc = nullptr;       // [row_count]: the summed accelerations the update kernels read as one split
+    float4 *rowsum = nullptr;        // [kSymGroups][row_count]: row-side sums per column group (launch_sym_rowsum)
+    int early_groups = 0, early_rows = 0;  // groups / leading rows whose sums the last force call already formed
+    hipEvent_t ev_part = nullptr;
     float *split_mass = nullptr;     // [n_splits]: the one mass of each split's bodies or NaN (pair-once tiles' fast path)
     bool sym_reduced = false;        // nbody_sym_reduce has run since the last forces
     int group_splits = 1, group_lo = 0, group_count = 0;
@@ -68,7 +74,8 @@ struct nbody_ctx {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_force, ev_update, ev_aux;  // launches not yet added to the totals
     std::vector<hipEvent_t> ev_pool;
-    double force_ms = 0, update_ms = 0, aux_ms = 0;  // aux: the pair-once mode's diagonal-tile launches
+    double force_ms = 0, update_ms = 0, aux_ms = 0;  // aux: what the pair-once mode runs on the auxiliary stream BESIDE the
+                                                      // tile launches (diagonal tiles, early summation)
     int64_t force_launches = 0, update_launches = 0, aux_launches = 0;
     std::string err;
 };
@@ -83,6 +90,8 @@ static int fail(nbody_ctx *c, int status, const std::string &msg)
         g_create_error = msg;
     return status;
 }
+
+static void free_sym_tiles(nbody_ctx *c);
 
 #define HIP_TRY(c, call)                                                                                   \
     do {                                                                                                   \
@@ -243,13 +252,12 @@ int nbody_destroy(nbody_ctx *c)
     if (c->vel) (void)hipFree(c->vel);
     if (c->eps_own) (void)hipFree(c->eps_own);
     if (c->reduce_dev) (void)hipFree(c->reduce_dev);
-    for (auto &kv : c->sym_tiles) {
-        if (kv.second.tiles) (void)hipFree(kv.second.tiles);
-        if (kv.second.diag) (void)hipFree(kv.second.diag);
-    }
+    free_sym_tiles(c);
     if (c->col_partials) (void)hipFree(c->col_partials);
     if (c->colparts_own) (void)hipFree(c->colparts_own);
     if (c->sym_acc) (void)hipFree(c->sym_acc);
+    if (c->rowsum) (void)hipFree(c->rowsum);
+    if (c->ev_part) (void)hipEventDestroy(c->ev_part);
     if (c->split_mass) (void)hipFree(c->split_mass);
     if (c->acc) (void)hipFree(c->acc);
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
@@ -490,6 +498,10 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
                                             "split_len needs less)");
         if (!c->sym_acc && c->row_count)
             HIP_TRY(c, hipMalloc((void **)&c->sym_acc, sizeof(float4) * (size_t)c->row_count));
+        if (!c->rowsum && c->row_count)
+            HIP_TRY(c, hipMalloc((void **)&c->rowsum, sizeof(float4) * (size_t)kSymGroups * (size_t)c->row_count));
+        if (!c->ev_part)
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
 
         if (!c->colparts) {
             if (!c->colparts_own && c->n_total)
@@ -543,7 +555,9 @@ int nbody_sym_reduce(nbody_ctx *c)
         return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_sym_colparts(c->col_partials, c->colparts, (int)c->n_total, (int)c->split_len, c->n_splits,
-                                   (int)(c->row_lo / c->split_len), c->group_splits, c->group_lo, c->group_count, c->stream));
+                                   (int)(c->row_lo / c->split_len), c->group_splits, c->group_lo + c->early_groups,
+                                   c->group_count - c->early_groups, c->stream));
+    c->early_groups = 0;
     c->sym_reduced = true;
     return NBODY_OK;
 }
@@ -569,8 +583,12 @@ static int summed_partials(nbody_ctx *c, const char *who, const float4 **partial
             return rc;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, launch_sym_finalize(reinterpret_cast<const float3 *>(c->partials), c->colparts, c->sym_acc, (int)c->row_lo, (int)c->row_count, (int)c->n_total,
-                                   (int)c->split_len, c->n_splits, c->group_splits, c->stream));
+    const int n_groups = (c->n_splits + c->group_splits - 1) / c->group_splits;
+    HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials), c->rowsum, (int)c->row_lo, (int)c->row_count,
+                                 (int)c->split_len, c->n_splits, c->group_splits, c->early_rows, (int)c->row_count, c->stream));
+    HIP_TRY(c, launch_sym_combine(c->rowsum, c->colparts, c->sym_acc, (int)c->row_lo, (int)c->row_count, (int)c->n_total, n_groups,
+                                  c->stream));
+    c->early_rows = 0;
     c->sym_reduced = false;
     *partials = c->sym_acc;
     *n_splits = 1;
@@ -607,6 +625,33 @@ int nbody_set_equal_mass_path(nbody_ctx *c, int on)
     if (!c)
         return NBODY_ERR_INVALID;
     c->equal_mass_path = on != 0;
+    c->acc_valid = false;
+    return NBODY_OK;
+}
+
+static void free_sym_tiles(nbody_ctx *c)
+{
+    for (auto &kv : c->sym_tiles) {
+        if (kv.second.tiles) (void)hipFree(kv.second.tiles);
+        if (kv.second.diag) (void)hipFree(kv.second.diag);
+    }
+    c->sym_tiles.clear();
+}
+
+int nbody_set_early_summation(nbody_ctx *c, int on)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    if (c->early_summation != (on != 0)) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_sym_tiles(c);  // the cached tile lists carry the launch split
+        if (c->step_graph) {
+            (void)hipGraphExecDestroy(c->step_graph);
+            c->step_graph = nullptr;
+        }
+    }
+    c->early_summation = on != 0;
     c->acc_valid = false;
     return NBODY_OK;
 }
@@ -702,26 +747,44 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             // instead of 128; workgroups are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md), so block k's tiles
             // take the launch slots congruent to k mod 8 and meet in one XCD's L2.
             static const bool blocked = !(getenv("NBODY_SYM_TILE_ORDER") && atoi(getenv("NBODY_SYM_TILE_ORDER")) == 0);
-            std::vector<std::vector<int2>> per_xcd(blocked ? 8 : 1);
-            int k = 0;
             const int B = blocked ? 8 : S;
-            for (int Rb = own_lo; Rb < own_hi; Rb += B)
-                for (int db = 1; db <= S / 2; db += B, ++k)
-                    for (int R = Rb; R < std::min(Rb + B, own_hi); ++R)
-                        for (int d = db; d < std::min(db + B, S / 2 + 1); ++d) {
-                            const int C = (R + d) % S;
-                            if (selected(C) && sym_rows_side(R, C, S))
-                                per_xcd[(size_t)k % per_xcd.size()].push_back(make_int2(R, C));
+            auto list_rows = [&](int r_lo, int r_hi) {  // the tiles with a row split in [r_lo, r_hi), in launch order
+                std::vector<std::vector<int2>> per_xcd(blocked ? 8 : 1);
+                int k = 0;
+                for (int Rb = r_lo; Rb < r_hi; Rb += B)
+                    for (int db = 1; db <= S / 2; db += B, ++k)
+                        for (int R = Rb; R < std::min(Rb + B, r_hi); ++R)
+                            for (int d = db; d < std::min(db + B, S / 2 + 1); ++d) {
+                                const int C = (R + d) % S;
+                                if (selected(C) && sym_rows_side(R, C, S))
+                                    per_xcd[(size_t)k % per_xcd.size()].push_back(make_int2(R, C));
+                            }
+                for (size_t j = 0, more = 1; more; ++j) {
+                    more = 0;
+                    for (auto &seq : per_xcd)
+                        if (j < seq.size()) {
+                            tiles.push_back(seq[j]);
+                            more = 1;
                         }
-            for (size_t j = 0, more = 1; more; ++j) {
-                more = 0;
-                for (auto &seq : per_xcd)
-                    if (j < seq.size()) {
-                        tiles.push_back(seq[j]);
-                        more = 1;
-                    }
-            }
+                }
+            };
+            // Early summation (one context that owns every row, all columns in one call, a system large enough for two
+            // launches): the tiles of all row groups but the last go first; while the last group's tiles run, the
+            // auxiliary stream already forms the column-side sums of the finished groups and the row-side sums of their
+            // rows -- the canonical order is by groups, so nothing about the result changes.  What stays behind the
+            // force pass is the last group's share of the summation (an eighth) and the combination.
+            const bool early_on = c->early_summation;
+            const int n_groups = (S + c->group_splits - 1) / c->group_splits;
+            const int r_split = (n_groups - 1) * c->group_splits;
+            const bool whole = c->row_lo == 0 && c->row_count == c->n_total && !complement && first == 0 && count == S;
             nbody_ctx::SymTiles t;
+            if (early_on && whole && n_groups >= 2 && (int64_t)S * S / 2 >= 32768) {
+                list_rows(own_lo, r_split);
+                t.n_early = (int)tiles.size();
+                list_rows(r_split, own_hi);
+            } else {
+                list_rows(own_lo, own_hi);
+            }
             HIP_TRY(c, hipSetDevice(c->device));
             if (!tiles.empty()) {
                 HIP_TRY(c, hipMalloc((void **)&t.tiles, sizeof(int2) * tiles.size()));
@@ -765,7 +828,37 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             HIP_TRY(c, launch_forces_symmetric_diag(sa, c->aux_stream));
         }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
-        {
+        c->early_groups = c->early_rows = 0;
+        const int n_early = it->second.n_early;
+        if (n_early > 0) {
+            sa.n_tiles = n_early;
+            {
+                TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone
+                HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
+            }
+            HIP_TRY(c, hipEventRecord(c->ev_part, c->stream));
+            sa.tiles = it->second.tiles + n_early;
+            sa.n_tiles = it->second.n - n_early;
+            {
+                TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);
+                HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
+            }
+            // beside the second launch: the sums of the groups the first one finished (the diagonal tiles are already done
+            // on this stream)
+            const int n_groups = (S + c->group_splits - 1) / c->group_splits;
+            const int rows_early = (int)std::min<int64_t>((int64_t)(n_groups - 1) * c->group_splits * L, c->row_count);
+            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_part, 0));
+            {
+                TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches, c->aux_stream, true);  // overlapped, like the diagonal
+                HIP_TRY(c, launch_sym_colparts(c->col_partials, c->colparts, (int)c->n_total, L, S, own_lo, c->group_splits,
+                                               c->group_lo, n_groups - 1, c->aux_stream));
+                HIP_TRY(c, launch_sym_rowsum(sa.row_partials, c->rowsum, (int)c->row_lo, (int)c->row_count, L, S, c->group_splits, 0,
+                                             rows_early, c->aux_stream));
+            }
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+            c->early_groups = n_groups - 1;
+            c->early_rows = rows_early;
+        } else {
             TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone: rocprofv3's time for it
             HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
         }

@@ -86,10 +86,13 @@ size_t symmetric_lds_bytes(int split_len);
 // for the own groups [group_lo, group_lo + group_count) and every body c.  colparts is [kSymGroups][n_total].
 hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
                                int split_lo, int group_splits, int group_lo, int group_count, hipStream_t stream);
-// acc[b] = sum over the groups g (ascending) of ( sum over C in g (ascending, where the tile (B(b), C) exists, and the
-// diagonal C == B(b)) of P_row[C][b]  +  colparts[g][b] ): the same association for any number of ranks.
-hipError_t launch_sym_finalize(const float3 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
-                               int n_total, int split_len, int n_splits, int group_splits, hipStream_t stream);
+// rowsum[g][b] = sum over C in group g (ascending, where the tile (B(b), C) exists, and the diagonal C == B(b)) of
+// P_row[d(B, C)][b] for the own rows [b_lo, b_hi); rowsum is [groups][row_count] float4.
+hipError_t launch_sym_rowsum(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count, int split_len, int n_splits,
+                             int group_splits, int b_lo, int b_hi, hipStream_t stream);
+// acc[b] = sum over the groups g (ascending) of ( rowsum[g][b] + colparts[g][b] ): the same association for any number of ranks.
+hipError_t launch_sym_combine(const float4 *rowsum, const float4 *colparts, float4 *acc, int row_lo, int row_count, int n_total,
+                              int n_groups, hipStream_t stream);
 
 // Partial accelerations of rows [row_lo,row_lo+row_count) from splits [split_first, split_first+split_count).
 // rows_per_lane in {1,2,4,8}.  eps2 == 0 selects the zero-distance-guarded variant.

@@ -764,15 +764,17 @@ __global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float3 *col_p
     colparts[(size_t)g * n_total + c] = make_float4(sx, sy, sz, 0.f);
 }
 
-__global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float3 *row_partials, const float4 *colparts, float4 *acc,
-                                                             int row_lo, int row_count, int n_total, int split_len,
-                                                             int n_splits, int group_splits)
+// rowsum[g][b] = sum over the column splits C of group g (ascending, where the tile (B(b), C) exists, and the diagonal
+// C == B(b)) of P_row[d(B, C)][b], for the own rows [b_lo, b_hi): the row-side half of the canonical summation.  It needs
+// only the tiles whose row side is b's split, so the rows of the groups a launch has finished can be summed while later
+// tiles still run.
+__global__ __launch_bounds__(kTile) void sym_rowsum_kernel(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count,
+                                                           int split_len, int n_splits, int group_splits, int b_lo, int b_hi)
 {
-    const int b = blockIdx.x * kTile + threadIdx.x;
-    if (b >= row_count)
+    const int b = b_lo + blockIdx.x * kTile + threadIdx.x;
+    if (b >= b_hi)
         return;
     const int B = (row_lo + b) / split_len;
-    float ax = 0.f, ay = 0.f, az = 0.f;
     for (int g = 0; g * group_splits < n_splits; ++g) {
         const int c0 = g * group_splits, c1 = min(c0 + group_splits, n_splits);
         float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -783,10 +785,25 @@ __global__ __launch_bounds__(kTile) void sym_finalize_kernel(const float3 *row_p
                 sy += v.y;
                 sz += v.z;
             }
+        rowsum[(size_t)g * row_count + b] = make_float4(sx, sy, sz, 0.f);
+    }
+}
+
+// acc[b] = sum over the groups g (ascending) of ( rowsum[g][b] + colparts[g][b] ): the same association for any number
+// of ranks and whether or not part of the sums was formed early.
+__global__ __launch_bounds__(kTile) void sym_combine_kernel(const float4 *rowsum, const float4 *colparts, float4 *acc, int row_lo,
+                                                            int row_count, int n_total, int n_groups)
+{
+    const int b = blockIdx.x * kTile + threadIdx.x;
+    if (b >= row_count)
+        return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int g = 0; g < n_groups; ++g) {
+        const float4 rs = rowsum[(size_t)g * row_count + b];
         const float4 cp = colparts[(size_t)g * n_total + row_lo + b];
-        ax += sx + cp.x;
-        ay += sy + cp.y;
-        az += sz + cp.z;
+        ax += rs.x + cp.x;
+        ay += rs.y + cp.y;
+        az += rs.z + cp.z;
     }
     acc[b] = make_float4(ax, ay, az, 0.f);
 }
@@ -801,13 +818,23 @@ hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int
     return hipGetLastError();
 }
 
-hipError_t launch_sym_finalize(const float3 *row_partials, const float4 *colparts, float4 *acc, int row_lo, int row_count,
-                               int n_total, int split_len, int n_splits, int group_splits, hipStream_t stream)
+hipError_t launch_sym_rowsum(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count, int split_len, int n_splits,
+                             int group_splits, int b_lo, int b_hi, hipStream_t stream)
+{
+    if (b_hi <= b_lo)
+        return hipSuccess;
+    hipLaunchKernelGGL(sym_rowsum_kernel, dim3((b_hi - b_lo + kTile - 1) / kTile), dim3(kTile), 0, stream, row_partials, rowsum,
+                       row_lo, row_count, split_len, n_splits, group_splits, b_lo, b_hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_combine(const float4 *rowsum, const float4 *colparts, float4 *acc, int row_lo, int row_count, int n_total,
+                              int n_groups, hipStream_t stream)
 {
     if (row_count <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sym_finalize_kernel, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, row_partials,
-                       colparts, acc, row_lo, row_count, n_total, split_len, n_splits, group_splits);
+    hipLaunchKernelGGL(sym_combine_kernel, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, rowsum, colparts, acc,
+                       row_lo, row_count, n_total, n_groups);
     return hipGetLastError();
 }
 

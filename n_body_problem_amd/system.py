@@ -272,6 +272,11 @@ class NBodySystem:
         every split down the general path (A/B measurement, tests)."""
         check(self._lib.nbody_set_equal_mass_path(self._ctx, 1 if on else 0), self._ctx)
 
+    def set_early_summation(self, on: bool) -> None:
+        """Pair-once mode on one context: sum the finished row groups beside the last group's tiles (on by default; the
+        result is bit-identical either way)."""
+        check(self._lib.nbody_set_early_summation(self._ctx, 1 if on else 0), self._ctx)
+
     def device_info(self) -> dict:
         out = (ctypes.c_int64 * 4)()
         name = ctypes.create_string_buffer(128)

@@ -475,6 +475,33 @@ def test_graph_replay_of_a_step_gives_the_same_bits(nb, mode, integrator):
     assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
 
 
+@pytest.mark.parametrize("integrator", ["kick_drift", "kdk"])
+def test_early_summation_changes_no_bit(nb, integrator):
+    """Pair-once mode, one context, a system large enough for two tile launches: the sums of the finished row groups are
+    formed on the auxiliary stream while the last group's tiles run.  The association is by groups either way, so the state
+    must equal the single-launch path bit for bit (also against two shards, which never sum early)."""
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 1 << 18, 3                       # 256 splits of 1024: 32 640 tiles
+    pos, vel = nb.plummer(n, seed=19)
+    pos[: n // 3, 3] *= 2.0                     # two mass species: both inner loops run
+    out = {}
+    for early in (True, False):
+        with nb.NBodySystem(n, split_len=1024) as s:
+            s.set_force_mode("pair_once")
+            s.set_integrator(integrator)
+            s.set_early_summation(early)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            s.step_n(steps, 1e-3, 1e-3)
+            out[early] = s.download()
+    assert np.array_equal(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])
+    with MultiGpuSystem(n, devices=[0, 0], force_mode="pair_once", integrator=integrator, transport="peer_copy") as m:
+        m.set_state(pos, vel)
+        m.step_n(steps, 1e-3, 1e-3)
+        p, v = m.download()
+    assert np.array_equal(p, out[True][0]) and np.array_equal(v, out[True][1])
+
+
 # ---- diagnostics -----------------------------------------------------------------------------------
 
 def test_energy_and_momentum_match_oracle(nb, oracle_mod):
