@@ -45,19 +45,27 @@ def main(tag, rnd, n, kern="force_kernel", mode=""):
                     vgpr = r.get("VGPR_Count")
                     out["kernel_name"] = r["Kernel_Name"]
                     out["lds_block_size"] = int(r["LDS_Block_Size"])
+    steps = 0
     for f in newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 durations.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            if "update_kernel" in r["Kernel_Name"]:
+                steps += 1
+    # launches of the force kernel per force pass (round 2: the pair-once mode launches its tiles in two parts)
+    per_pass = max(1, round(len(durations) / steps)) if steps else 1
+    out["force_launches_per_pass"] = per_pass
     mean = {k: sum(v) / len(v) for k, v in counters.items()}
     out["counters_per_launch"] = mean
     out["avg_launch_ms_kernel_trace"] = sum(durations) / len(durations) if durations else None
+    out["force_pass_ms_kernel_trace"] = out["avg_launch_ms_kernel_trace"] * per_pass if durations else None
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         fetch = mean["FETCH_SIZE"] * 1024.0 * 2.0   # KiB -> B, x2: gfx950 counts 128-B requests as 64 B
         write = mean["WRITE_SIZE"] * 1024.0
         out["hbm_read_bytes_per_force_launch"] = fetch
         out["hbm_write_bytes_per_force_launch"] = write
         out["hbm_bytes_per_force_launch"] = fetch + write
+        out["hbm_bytes_per_force_pass"] = (fetch + write) * per_pass
         if durations:
             out["hbm_GBps"] = (fetch + write) / (out["avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
     if "GRBM_GUI_ACTIVE" in mean and durations:
@@ -70,7 +78,7 @@ def main(tag, rnd, n, kern="force_kernel", mode=""):
         if "SQ_WAVE_CYCLES" in mean:
             out["mean_waves_per_simd"] = mean["SQ_WAVE_CYCLES"] * 4.0 / (cyc * 1024.0)
         if "SQ_INSTS_VALU" in mean:
-            inter = float(n) * float(n) / 64.0   # wave64 instructions' worth of ORDERED interactions
+            inter = float(n) * float(n) / 64.0 / per_pass   # wave64 instructions' worth of ORDERED interactions per launch
             out["valu_instructions_per_interaction"] = mean["SQ_INSTS_VALU"] / inter
             out["simd_cycles_per_interaction"] = cyc * 1024.0 / inter
     if all(k in mean for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")) and durations:
