@@ -380,6 +380,10 @@ def main():
             "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
             "update_ms_per_step": tm["update_ms"] / args.steps,
             "overlapped_aux_ms_per_step": tm.get("aux_ms", 0.0) / args.steps,   # diagonal tiles + early summation, beside the tiles
+            # pair-once mode on one context: the tile launches per pass and what the two partial-sum arrays hold (two of the
+            # parts; n^2 / split_len 12-byte entries would be the whole pass)
+            "summation_parts": tm["force_launches"] // max(1, args.steps) if mode == "pair_once" and world == 1 else None,
+            "partial_sum_bytes": system.partial_sum_bytes() if hasattr(system, "partial_sum_bytes") else None,
             "device": info,
             "sanity": sanity,
         }

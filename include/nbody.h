@@ -159,7 +159,7 @@ int nbody_timing_enable(nbody_ctx *ctx, int on);
 /* out6 = {force_ms, force launches, update_ms, update launches, auxiliary ms, auxiliary launches}: the totals are SUMS of
  * per-launch durations (launches that overlap on two streams each count in full), not wall time.  force = the dominant
  * force kernel; update = what runs behind the force pass (summation, update, kicks); auxiliary = what the pair-once mode
- * runs on its second stream BESIDE the tile launches (the diagonal tiles, the early summation of the finished row
+ * runs on its second stream BESIDE the tile launches (the diagonal tiles, the summation of the finished row
  * groups) -- stretched by the sharing, hidden in wall time.  Waits for every recorded launch. */
 int nbody_timing_read_ex(nbody_ctx *ctx, double *out6);
 int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches, double *update_ms,
@@ -182,10 +182,11 @@ enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
  * summation order, so they must not depend on the sharding): 1024 from 204 800 to 2^21 bodies -- the kernel's rows per
  * pass, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles below that (small systems
  * need more, smaller tiles to fill the chip), then 2048 (N = 2^22) and 4096, so that the partial sums
- * (n_total^2 / split_len entries of 12 bytes over all contexts: 12.9 GB at N = 2^20, 103 GB at N = 2^22) would still
- * fit one GPU. */
+ * of one pass (n_total^2 / split_len entries of 12 bytes over all contexts: 12.9 GB at N = 2^20, 77 GB at N = 2^22) would
+ * still fit one GPU even in one summation part (nbody_set_summation_parts; a single context holds a quarter by default). */
 int64_t nbody_pair_once_split_len(int64_t n_total);
 #define NBODY_SYM_GROUPS 8
+#define NBODY_DEFAULT_SUMMATION_PARTS 8
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 /* The exchange buffer of the pair-once mode: NBODY_SYM_GROUPS x n_total x float4 on the device, group-major.
  * d_buf is borrowed (NULL: a buffer the context owns -- enough for a single context).  nbody_sym_reduce writes the
@@ -218,12 +219,20 @@ int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
  * sum of m x term).  0 switches it off: every split takes the general path (A/B measurement, tests). */
 int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
 
-/* Early summation (pair-once mode, one context that owns every row; on by default).  The partial sums are added in row
- * groups (NBODY_SYM_GROUPS), so the tiles are launched in two parts -- every group but the last, then the last -- and while
- * the last group's tiles run, an auxiliary stream already forms the sums of the finished groups: of the summation only the
- * last group's share (an eighth) and the combination stay behind the force pass.  The result does not change by a bit
- * (the association is by groups either way); 0 restores the single launch followed by the whole summation. */
+/* Summation parts (pair-once mode, one context that owns every row, all columns in one force call).  The partial sums are
+ * added in row groups (NBODY_SYM_GROUPS), so the tiles can be launched in parts of whole groups, and while one part's
+ * tiles run an auxiliary stream already forms the sums of the part before it: only the last part's share of the
+ * summation and the combination stay behind the force pass.  The result does not change by a bit (the association is by
+ * groups either way).  parts = 1: one launch, then the whole summation.  2: every group but the last, then the last (one
+ * extra launch tail; the partial-sum arrays hold the whole pass: n^2 / split_len 12-byte entries, 12.9 GB at N = 2^20).
+ * 4, 8: equal parts whose arrays live in two slots used in turn: 2/parts of that (8 parts: 3.2 GB at N = 2^20, 19 GB at
+ * 2^22), for one launch tail (~0.2 ms) per extra part.  0: the default (NBODY_DEFAULT_SUMMATION_PARTS).  Systems too small
+ * for several launches, shards and column-range calls always take one part.  nbody_set_early_summation(on) is
+ * nbody_set_summation_parts(on ? 0 : 1). */
+int nbody_set_summation_parts(nbody_ctx *ctx, int parts);
 int nbody_set_early_summation(nbody_ctx *ctx, int on);
+/* Bytes of partial-sum arrays the context holds at the moment (they are allocated by the first force call and only grow). */
+int64_t nbody_partial_sum_bytes(const nbody_ctx *ctx);
 
 /* Device facts for the roofline: out = {compute units, max clock MHz, wavefront size, LDS bytes per CU}. */
 int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);

@@ -21,7 +21,7 @@ struct nbody_ctx {
     int n_splits = 0;
     int rows_per_lane = 0;  // 0 = pick per launch
     bool equal_mass_path = true;  // splits whose bodies share one mass take the inner loop without mass multiplies
-    bool early_summation = true;  // pair-once mode, one context: sums of the finished row groups beside the last group's tiles
+    int sum_parts = 0;  // pair-once mode, one context: launches the row groups are cut into (nbody_set_summation_parts)
     int force_mode = NBODY_FORCE_ONE_SIDED;
     int integrator = NBODY_INTEGRATOR_KICK_DRIFT;
     float4 *acc = nullptr;      // kick-drift-kick mode: accelerations of the own rows at the current positions
@@ -29,17 +29,28 @@ struct nbody_ctx {
     const float *eps_pp = nullptr;  // per-particle softening lengths in use, n_total floats (borrowed or eps_own), or NULL
     float *eps_own = nullptr;       // the copy nbody_upload_particle_softening made
     // pair-once mode (nbody_symmetric.hip)
-    // tiles: first n_early (those whose row split lies in every group but the last: their sums are formed on the auxiliary
-    // stream while the remaining n - n_early run), then the rest; n_early = 0: one launch
-    struct SymTiles { int2 *tiles = nullptr; int n = 0, n_early = 0; int2 *diag = nullptr; int n_diag = 0; };
-    std::map<std::tuple<int, int, bool>, SymTiles> sym_tiles;  // per column range asked for: its (R, C) tiles
-    float3 *col_partials = nullptr;  // [own splits][n_splits / 2][split_len] 12-byte entries, see SymArgs
+    // One force call = one or more parts: a part is a run of whole row groups whose tiles go in one launch and whose partial
+    // sums are added up (on the auxiliary stream, beside the next part's tiles) as soon as that launch is over.  With more than
+    // two parts the partial sums live in two buffer slots used in turn: the arrays hold two parts, not the whole pass.
+    struct SymPart {
+        int g0 = 0, g1 = 0;              // row groups [g0, g1)
+        int split_lo = 0, split_hi = 0;  // = row splits [split_lo, split_hi)
+        int64_t b0 = 0, rows = 0;        // = rows [b0, b0 + rows) of this context
+        int2 *tiles = nullptr, *diag = nullptr;
+        int n_tiles = 0, n_diag = 0;
+        size_t row_off = 0, col_off = 0;  // where the part's [n_splits/2+1][rows] and [splits][n_splits/2][split_len] arrays
+                                          // start in partials / col_partials, in 12-byte entries
+    };
+    struct SymPlan { std::vector<SymPart> parts; size_t row_entries = 0, col_entries = 0; };
+    std::map<std::tuple<int, int, bool>, SymPlan> sym_plans;  // per column range asked for
+    const SymPart *pending = nullptr;  // the part of the last force call whose sums are still to be formed (the last one)
+    std::vector<hipEvent_t> ev_tiles, ev_red;  // per part: tile launch over / its sums formed (the slot is free again)
+    float3 *col_partials = nullptr;  // column-side partial sums, see SymArgs; sized by the plan (ensure_sym_buffers)
+    size_t col_entries = 0;
     float4 *colparts = nullptr;      // [kSymGroups][n_total] in use: the caller's (nbody_sym_set_colparts) or colparts_own
     float4 *colparts_own = nullptr;
     float4 *sym_acc = nullptr;       // [row_count]: the summed accelerations the update kernels read as one split
     float4 *rowsum = nullptr;        // [kSymGroups][row_count]: row-side sums per column group (launch_sym_rowsum)
-    int early_groups = 0, early_rows = 0;  // groups / leading rows whose sums the last force call already formed
-    hipEvent_t ev_part = nullptr;
     float *split_mass = nullptr;     // [n_splits]: the one mass of each split's bodies or NaN (pair-once tiles' fast path)
     bool sym_reduced = false;        // nbody_sym_reduce has run since the last forces
     int group_splits = 1, group_lo = 0, group_count = 0;
@@ -92,6 +103,7 @@ static int fail(nbody_ctx *c, int status, const std::string &msg)
 }
 
 static void free_sym_tiles(nbody_ctx *c);
+static constexpr int kDefaultSumParts = NBODY_DEFAULT_SUMMATION_PARTS;  // see forces_impl; measured in profiles/r02_summation_parts.txt
 
 #define HIP_TRY(c, call)                                                                                   \
     do {                                                                                                   \
@@ -140,9 +152,10 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
     // 1024 = the pair-once kernel's rows per pass (4 waves x 64 lanes x 4 rows): shorter splits idle waves, longer ones
     // coarsen the grid (at N = 2^20 one of 8 ranks measured 24.4 ms per step with 1024, 25.8 with 2048, 46.9 with 512;
     // N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms; 4096 leaves 3 workgroups per CU: 441 against 392 ms for one of 8 ranks
-    // at N = 2^22).  The two partial-sum arrays together hold n_total^2 / split_len entries of 12 bytes: 12.9 GB at
-    // N = 2^20; the length doubles where 16-byte entries (round 1's layout: the rule is kept, split boundaries define
-    // the summation order) would pass 150 GB -- 2048 at N = 2^22: 103 GB, one GPU can still hold it.
+    // at N = 2^22).  One pass writes n_total^2 / split_len partial sums of 12 bytes into the two arrays: 12.9 GB at
+    // N = 2^20 (a single context holds two of its eight summation parts at a time, 3.2 GB); the length doubles where
+    // 16-byte entries (round 1's layout: the rule is kept, split boundaries define the summation order) would pass
+    // 150 GB -- 2048 at N = 2^22: 77 GB per pass, one GPU can still hold it whole.
     // Below ~200 000 bodies 1024-body tiles are too few to fill 256 CUs x 5 workgroups evenly (N = 131072: 2016 tiles):
     // the splits shrink to n_total / 200, in whole 256-body tiles, and the tile kernel runs with 2 or 1 wave per workgroup.
     const double pairs16 = 16.0 * (double)n_total * (double)n_total;
@@ -257,7 +270,8 @@ int nbody_destroy(nbody_ctx *c)
     if (c->colparts_own) (void)hipFree(c->colparts_own);
     if (c->sym_acc) (void)hipFree(c->sym_acc);
     if (c->rowsum) (void)hipFree(c->rowsum);
-    if (c->ev_part) (void)hipEventDestroy(c->ev_part);
+    for (auto &e : c->ev_tiles) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_red) (void)hipEventDestroy(e);
     if (c->split_mass) (void)hipFree(c->split_mass);
     if (c->acc) (void)hipFree(c->acc);
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
@@ -491,18 +505,17 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         c->group_lo = split_lo / gs;
         c->group_count = c->row_count ? (split_hi + gs - 1) / gs - c->group_lo : 0;
         HIP_TRY(c, hipSetDevice(c->device));
-        if (!c->col_partials && c->row_count && c->n_splits > 1 &&
-            hipMalloc((void **)&c->col_partials, sizeof(float3) * (size_t)(split_hi - split_lo) * (size_t)(c->n_splits / 2) *
-                                                     (size_t)c->split_len) != hipSuccess)
-            return fail(c, NBODY_ERR_ALLOC, "nbody_set_force_mode: hipMalloc of the column-side partial sums failed (a longer "
-                                            "split_len needs less)");
         if (!c->sym_acc && c->row_count)
             HIP_TRY(c, hipMalloc((void **)&c->sym_acc, sizeof(float4) * (size_t)c->row_count));
         if (!c->rowsum && c->row_count)
             HIP_TRY(c, hipMalloc((void **)&c->rowsum, sizeof(float4) * (size_t)kSymGroups * (size_t)c->row_count));
-        if (!c->ev_part)
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
-
+        while (c->ev_tiles.size() < (size_t)kSymGroups) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(c, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            c->ev_tiles.push_back(a);
+            HIP_TRY(c, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            c->ev_red.push_back(b);
+        }
         if (!c->colparts) {
             if (!c->colparts_own && c->n_total)
                 HIP_TRY(c, hipMalloc((void **)&c->colparts_own, sizeof(float4) * (size_t)kSymGroups * (size_t)c->n_total));
@@ -554,10 +567,12 @@ int nbody_sym_reduce(nbody_ctx *c)
     if (rc != NBODY_OK)
         return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, launch_sym_colparts(c->col_partials, c->colparts, (int)c->n_total, (int)c->split_len, c->n_splits,
-                                   (int)(c->row_lo / c->split_len), c->group_splits, c->group_lo + c->early_groups,
-                                   c->group_count - c->early_groups, c->stream));
-    c->early_groups = 0;
+    if (!c->pending)
+        return fail(c, NBODY_ERR_STATE, "nbody_sym_reduce: no force call since the last update");
+    // the groups of the last part; the earlier parts' sums were formed beside the tile launches
+    const nbody_ctx::SymPart &p = *c->pending;
+    HIP_TRY(c, launch_sym_colparts(c->col_partials + p.col_off, c->colparts, (int)c->n_total, (int)c->split_len, c->n_splits,
+                                   p.split_lo, c->group_splits, p.g0, p.g1 - p.g0, c->stream));
     c->sym_reduced = true;
     return NBODY_OK;
 }
@@ -584,11 +599,12 @@ static int summed_partials(nbody_ctx *c, const char *who, const float4 **partial
     }
     HIP_TRY(c, hipSetDevice(c->device));
     const int n_groups = (c->n_splits + c->group_splits - 1) / c->group_splits;
-    HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials), c->rowsum, (int)c->row_lo, (int)c->row_count,
-                                 (int)c->split_len, c->n_splits, c->group_splits, c->early_rows, (int)c->row_count, c->stream));
+    const nbody_ctx::SymPart &p = *c->pending;
+    HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + p.row_off, c->rowsum + p.b0,
+                                 (int)(c->row_lo + p.b0), (int)p.rows, (int)c->split_len, c->n_splits, c->group_splits,
+                                 (int)c->row_count, c->stream));
     HIP_TRY(c, launch_sym_combine(c->rowsum, c->colparts, c->sym_acc, (int)c->row_lo, (int)c->row_count, (int)c->n_total, n_groups,
                                   c->stream));
-    c->early_rows = 0;
     c->sym_reduced = false;
     *partials = c->sym_acc;
     *n_splits = 1;
@@ -631,29 +647,40 @@ int nbody_set_equal_mass_path(nbody_ctx *c, int on)
 
 static void free_sym_tiles(nbody_ctx *c)
 {
-    for (auto &kv : c->sym_tiles) {
-        if (kv.second.tiles) (void)hipFree(kv.second.tiles);
-        if (kv.second.diag) (void)hipFree(kv.second.diag);
-    }
-    c->sym_tiles.clear();
+    for (auto &kv : c->sym_plans)
+        for (auto &p : kv.second.parts) {
+            if (p.tiles) (void)hipFree(p.tiles);
+            if (p.diag) (void)hipFree(p.diag);
+        }
+    c->sym_plans.clear();
+    c->pending = nullptr;
 }
 
-int nbody_set_early_summation(nbody_ctx *c, int on)
+int nbody_set_summation_parts(nbody_ctx *c, int parts)
 {
-    if (!c)
-        return NBODY_ERR_INVALID;
-    if (c->early_summation != (on != 0)) {
+    if (!c || !(parts == 0 || parts == 1 || parts == 2 || parts == 4 || parts == 8))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_summation_parts: expected 0 (default), 1, 2, 4 or 8");
+    if (c->sum_parts != parts) {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        free_sym_tiles(c);  // the cached tile lists carry the launch split
+        HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+        free_sym_tiles(c);  // the cached plans carry the cut into parts
+        std::fill(c->split_done.begin(), c->split_done.end(), 0);
         if (c->step_graph) {
             (void)hipGraphExecDestroy(c->step_graph);
             c->step_graph = nullptr;
         }
     }
-    c->early_summation = on != 0;
+    c->sum_parts = parts;
     c->acc_valid = false;
     return NBODY_OK;
+}
+
+int nbody_set_early_summation(nbody_ctx *c, int on) { return nbody_set_summation_parts(c, on ? 0 : 1); }
+
+int64_t nbody_partial_sum_bytes(const nbody_ctx *c)
+{
+    return c ? (int64_t)(c->partials_entries * sizeof(float4) + c->col_entries * sizeof(float3)) : 0;
 }
 
 int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
@@ -684,14 +711,10 @@ static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
     return 1;
 }
 
-// The partial-sum array of the current force mode (a mode switch may need a larger one).
+// The partial-sum array of the one-sided mode (a mode switch may need a larger one).
 static int ensure_partials(nbody_ctx *c)
 {
-    // one-sided: [n_splits][rows] float4; pair-once: [n_splits / 2 + 1][rows] 12-byte entries (counted in float4 units)
-    const bool sym = c->force_mode == NBODY_FORCE_SYMMETRIC;
-    const size_t slots = sym ? (size_t)c->n_splits / 2 + 1 : (size_t)c->n_splits;
-    const size_t entries = sym ? (slots * (size_t)c->row_count * sizeof(float3) + sizeof(float4) - 1) / sizeof(float4)
-                               : slots * (size_t)c->row_count;
+    const size_t entries = (size_t)c->n_splits * (size_t)c->row_count;  // [n_splits][rows] float4
     if (entries <= c->partials_entries)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -705,6 +728,40 @@ static int ensure_partials(nbody_ctx *c)
         return fail(c, NBODY_ERR_ALLOC, "partial sums: hipMalloc of " + std::to_string(sizeof(float4) * entries >> 20) +
                                             " MiB failed (a longer split_len needs less)");
     c->partials_entries = entries;
+    return NBODY_OK;
+}
+
+// The two partial-sum arrays of the pair-once mode, in 12-byte entries: what the plan of a force call needs (the whole pass,
+// or two parts of it).  They only grow.
+static int ensure_sym_buffers(nbody_ctx *c, size_t row_entries, size_t col_entries)
+{
+    const size_t row_f4 = (row_entries * sizeof(float3) + sizeof(float4) - 1) / sizeof(float4);
+    if (row_f4 <= c->partials_entries && col_entries <= c->col_entries)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    if (row_f4 > c->partials_entries) {
+        if (c->partials)
+            (void)hipFree(c->partials);
+        c->partials = nullptr;
+        c->partials_entries = 0;
+        if (hipMalloc((void **)&c->partials, sizeof(float4) * row_f4) != hipSuccess)
+            return fail(c, NBODY_ERR_ALLOC, "row-side partial sums: hipMalloc of " + std::to_string(sizeof(float4) * row_f4 >> 20) +
+                                                " MiB failed (more summation parts or a longer split_len need less)");
+        c->partials_entries = row_f4;
+    }
+    if (col_entries > c->col_entries) {
+        if (c->col_partials)
+            (void)hipFree(c->col_partials);
+        c->col_partials = nullptr;
+        c->col_entries = 0;
+        if (hipMalloc((void **)&c->col_partials, sizeof(float3) * col_entries) != hipSuccess)
+            return fail(c, NBODY_ERR_ALLOC, "column-side partial sums: hipMalloc of " +
+                                                std::to_string(sizeof(float3) * col_entries >> 20) +
+                                                " MiB failed (more summation parts or a longer split_len need less)");
+        c->col_entries = col_entries;
+    }
     return NBODY_OK;
 }
 
@@ -723,25 +780,22 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return fail(c, NBODY_ERR_INVALID, std::string(who) + ": column range must be split-aligned and inside [0,n_total]");
     if (c->row_count == 0 || c->n_total == 0)
         return NBODY_OK;
-    {
-        int rc = ensure_partials(c);
-        if (rc != NBODY_OK)
-            return rc;
-    }
     const int first = (int)(col_lo / c->split_len);
     const int count = (int)((col_count + c->split_len - 1) / c->split_len);
     if (c->force_mode == NBODY_FORCE_SYMMETRIC) {
-        // this context's tiles with a column split in the range asked for (cached per range)
+        // this context's tiles with a column split in the range asked for, cut into parts (cached per range)
         const int S = c->n_splits, L = (int)c->split_len;
         const int own_lo = (int)(c->row_lo / L), own_hi = (int)((c->row_lo + c->row_count + L - 1) / L);
+        const bool whole = c->row_lo == 0 && c->row_count == c->n_total && !complement && first == 0 && count == S;
+        if (!whole && c->pending && c->pending->g1 - c->pending->g0 != c->group_count)
+            for (int sp = 0; sp < S; ++sp)
+                if (c->split_done[(size_t)sp])
+                    return fail(c, NBODY_ERR_STATE, std::string(who) + ": a column range after a call for all columns in several "
+                                                                        "summation parts: the earlier parts are already summed");
         auto key = std::make_tuple(first, count, complement);
-        auto it = c->sym_tiles.find(key);
-        if (it == c->sym_tiles.end()) {
-            std::vector<int2> tiles, diag;
+        auto it = c->sym_plans.find(key);
+        if (it == c->sym_plans.end()) {
             auto selected = [&](int C) { return (C >= first && C < first + count) != complement; };
-            for (int R = own_lo; R < own_hi; ++R)
-                if (selected(R))
-                    diag.push_back(make_int2(R, R));
             // Launch order = L2 locality (speed only; every tile has its own outputs).  The tile of row split R and ring
             // distance d has column split (R + d) mod S.  Blocks of 8 row splits x 8 distances touch 23 splits' bodies
             // instead of 128; workgroups are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md), so block k's tiles
@@ -749,6 +803,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             static const bool blocked = !(getenv("NBODY_SYM_TILE_ORDER") && atoi(getenv("NBODY_SYM_TILE_ORDER")) == 0);
             const int B = blocked ? 8 : S;
             auto list_rows = [&](int r_lo, int r_hi) {  // the tiles with a row split in [r_lo, r_hi), in launch order
+                std::vector<int2> tiles;
                 std::vector<std::vector<int2>> per_xcd(blocked ? 8 : 1);
                 int k = 0;
                 for (int Rb = r_lo; Rb < r_hi; Rb += B)
@@ -767,49 +822,85 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                             more = 1;
                         }
                 }
+                return tiles;
             };
-            // Early summation (one context that owns every row, all columns in one call, a system large enough for two
-            // launches): the tiles of all row groups but the last go first; while the last group's tiles run, the
-            // auxiliary stream already forms the column-side sums of the finished groups and the row-side sums of their
-            // rows -- the canonical order is by groups, so nothing about the result changes.  What stays behind the
-            // force pass is the last group's share of the summation (an eighth) and the combination.
-            const bool early_on = c->early_summation;
+            // Summation parts (one context that owns every row, all columns in one call, a system large enough for several
+            // launches): the canonical order is by row groups, so a part's sums can be formed as soon as its launch is over,
+            // on the auxiliary stream beside the next part's tiles, and nothing about the result changes.  What stays behind
+            // the force pass is the last part's share of the summation and the combination.  2 parts = 7 groups + 1 (one
+            // extra launch tail, the arrays hold the whole pass); 4 or 8 equal parts keep two parts' arrays.
             const int n_groups = (S + c->group_splits - 1) / c->group_splits;
-            const int r_split = (n_groups - 1) * c->group_splits;
-            const bool whole = c->row_lo == 0 && c->row_count == c->n_total && !complement && first == 0 && count == S;
-            nbody_ctx::SymTiles t;
-            if (early_on && whole && n_groups >= 2 && (int64_t)S * S / 2 >= 32768) {
-                list_rows(own_lo, r_split);
-                t.n_early = (int)tiles.size();
-                list_rows(r_split, own_hi);
-            } else {
-                list_rows(own_lo, own_hi);
+            int K = c->sum_parts ? c->sum_parts : kDefaultSumParts;
+            // below 32768 tiles (N = 2^18) an extra launch costs more than the summation it hides; the variable is for tests
+            const char *min_env = getenv("NBODY_SYM_PARTS_MIN_TILES");
+            const int64_t min_tiles = min_env ? atoll(min_env) : 32768;
+            if (!whole || (int64_t)S * S / 2 < min_tiles || n_groups < 2)
+                K = 1;
+            else if (K > 2 && n_groups % K != 0)
+                K = 2;
+            nbody_ctx::SymPlan plan;
+            for (int p = 0; p < K; ++p) {
+                nbody_ctx::SymPart part;
+                if (K == 1) {
+                    part.g0 = c->group_lo;
+                    part.g1 = c->group_lo + c->group_count;
+                } else if (K == 2) {
+                    part.g0 = p ? n_groups - 1 : 0;
+                    part.g1 = p ? n_groups : n_groups - 1;
+                } else {
+                    part.g0 = p * (n_groups / K);
+                    part.g1 = (p + 1) * (n_groups / K);
+                }
+                part.split_lo = std::max(own_lo, part.g0 * c->group_splits);
+                part.split_hi = std::min(own_hi, part.g1 * c->group_splits);
+                part.b0 = (int64_t)part.split_lo * L - c->row_lo;
+                part.rows = std::min<int64_t>((int64_t)part.split_hi * L, c->row_lo + c->row_count) - (int64_t)part.split_lo * L;
+                const size_t row_need = ((size_t)S / 2 + 1) * (size_t)part.rows;
+                const size_t col_need = (size_t)(part.split_hi - part.split_lo) * (size_t)(S / 2) * (size_t)L;
+                if (K > 2) {  // two slots used in turn
+                    plan.row_entries = std::max(plan.row_entries, 2 * row_need);
+                    plan.col_entries = std::max(plan.col_entries, 2 * col_need);
+                } else {
+                    part.row_off = plan.row_entries;
+                    part.col_off = plan.col_entries;
+                    plan.row_entries += row_need;
+                    plan.col_entries += col_need;
+                }
+                std::vector<int2> tiles = list_rows(part.split_lo, part.split_hi), diag;
+                for (int R = part.split_lo; R < part.split_hi; ++R)
+                    if (selected(R))
+                        diag.push_back(make_int2(R, R));
+                HIP_TRY(c, hipSetDevice(c->device));
+                if (!tiles.empty()) {
+                    HIP_TRY(c, hipMalloc((void **)&part.tiles, sizeof(int2) * tiles.size()));
+                    HIP_TRY(c, hipMemcpy(part.tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice));
+                }
+                if (!diag.empty()) {
+                    HIP_TRY(c, hipMalloc((void **)&part.diag, sizeof(int2) * diag.size()));
+                    HIP_TRY(c, hipMemcpy(part.diag, diag.data(), sizeof(int2) * diag.size(), hipMemcpyHostToDevice));
+                }
+                part.n_tiles = (int)tiles.size();
+                part.n_diag = (int)diag.size();
+                plan.parts.push_back(part);
             }
-            HIP_TRY(c, hipSetDevice(c->device));
-            if (!tiles.empty()) {
-                HIP_TRY(c, hipMalloc((void **)&t.tiles, sizeof(int2) * tiles.size()));
-                HIP_TRY(c, hipMemcpy(t.tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice));
-            }
-            if (!diag.empty()) {
-                HIP_TRY(c, hipMalloc((void **)&t.diag, sizeof(int2) * diag.size()));
-                HIP_TRY(c, hipMemcpy(t.diag, diag.data(), sizeof(int2) * diag.size(), hipMemcpyHostToDevice));
-            }
-            t.n = (int)tiles.size();
-            t.n_diag = (int)diag.size();
-            it = c->sym_tiles.emplace(key, t).first;
+            if (K > 2)
+                for (int p = 0; p < K; ++p) {
+                    plan.parts[(size_t)p].row_off = (p & 1) * (plan.row_entries / 2);
+                    plan.parts[(size_t)p].col_off = (p & 1) * (plan.col_entries / 2);
+                }
+            it = c->sym_plans.emplace(key, std::move(plan)).first;
         }
+        const nbody_ctx::SymPlan &plan = it->second;
+        {
+            int rc = ensure_sym_buffers(c, plan.row_entries, plan.col_entries);
+            if (rc != NBODY_OK)
+                return rc;
+        }
+        const int K = (int)plan.parts.size();
         SymArgs sa;
         sa.pos = reinterpret_cast<const float4 *>(d_pos);
-        sa.row_partials = reinterpret_cast<float3 *>(c->partials);
-        sa.col_partials = c->col_partials;
-        sa.tiles = it->second.tiles;
-        sa.n_tiles = it->second.n;
-        sa.diag_tiles = it->second.diag;
-        sa.n_diag = it->second.n_diag;
         sa.n_total = (int)c->n_total;
         sa.split_len = L;
-        sa.row_lo = (int)c->row_lo;
-        sa.row_count = (int)c->row_count;
         sa.eps2 = softening * softening;
         sa.eps_pp = c->eps_pp;
         sa.split_mass = c->split_mass;
@@ -817,57 +908,73 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         // keeps the one-column loop for A/B measurement
         static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 1;
         sa.packed = packed_env;
+        auto part_args = [&](const nbody_ctx::SymPart &p) {
+            sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;
+            sa.col_partials = c->col_partials + p.col_off;
+            sa.tiles = p.tiles;
+            sa.n_tiles = p.n_tiles;
+            sa.diag_tiles = p.diag;
+            sa.n_diag = p.n_diag;
+            sa.row_lo = (int)(c->row_lo + p.b0);
+            sa.row_count = (int)p.rows;
+        };
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, launch_split_mass(sa.pos, c->split_mass, sa.n_total, L, c->equal_mass_path, c->stream));
-        // the diagonal tiles (pairs inside one split; their own slot of the row-side array) on the auxiliary stream, beside
-        // the tile launch: 0.56 ms at N = 2^20 that no longer stands between the tiles and the summation
+        // The auxiliary stream, beside the tile launches: a part's diagonal tiles (pairs inside one split; their own slot of
+        // the row-side array: 0.56 ms at N = 2^20 that no longer stands between the tiles and the summation), and, once the
+        // part's tile launch is over, its column-side sums per group and the row-side sums of its rows.  With two slots the
+        // diagonal tiles of part p + 2 follow the sums of part p on this stream, and the tile launch of part p + 2 waits for
+        // them (they ran beside part p + 1's tiles).
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-        {
+        auto diag_launch = [&](int p) -> int {
+            part_args(plan.parts[(size_t)p]);
             TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches, c->aux_stream, true);  // reported separately
             HIP_TRY(c, launch_forces_symmetric_diag(sa, c->aux_stream));
-        }
-        HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
-        c->early_groups = c->early_rows = 0;
-        const int n_early = it->second.n_early;
-        if (n_early > 0) {
-            sa.n_tiles = n_early;
+            return NBODY_OK;
+        };
+        for (int p = 0; p < std::min(K, 2); ++p)
+            if (int rc = diag_launch(p))
+                return rc;
+        for (int p = 0; p < K; ++p) {
+            const nbody_ctx::SymPart &part = plan.parts[(size_t)p];
+            if (K > 2 && p >= 2)
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_red[(size_t)p - 2], 0));
+            part_args(part);
             {
                 TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone
                 HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
             }
-            HIP_TRY(c, hipEventRecord(c->ev_part, c->stream));
-            sa.tiles = it->second.tiles + n_early;
-            sa.n_tiles = it->second.n - n_early;
-            {
-                TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);
-                HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
-            }
-            // beside the second launch: the sums of the groups the first one finished (the diagonal tiles are already done
-            // on this stream)
-            const int n_groups = (S + c->group_splits - 1) / c->group_splits;
-            const int rows_early = (int)std::min<int64_t>((int64_t)(n_groups - 1) * c->group_splits * L, c->row_count);
-            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_part, 0));
+            if (p == K - 1)
+                break;
+            HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_tiles[(size_t)p], 0));
             {
                 TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches, c->aux_stream, true);  // overlapped, like the diagonal
-                HIP_TRY(c, launch_sym_colparts(c->col_partials, c->colparts, (int)c->n_total, L, S, own_lo, c->group_splits,
-                                               c->group_lo, n_groups - 1, c->aux_stream));
-                HIP_TRY(c, launch_sym_rowsum(sa.row_partials, c->rowsum, (int)c->row_lo, (int)c->row_count, L, S, c->group_splits, 0,
-                                             rows_early, c->aux_stream));
+                HIP_TRY(c, launch_sym_colparts(c->col_partials + part.col_off, c->colparts, (int)c->n_total, L, S, part.split_lo,
+                                               c->group_splits, part.g0, part.g1 - part.g0, c->aux_stream));
+                HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + part.row_off, c->rowsum + part.b0,
+                                             (int)(c->row_lo + part.b0), (int)part.rows, L, S, c->group_splits, (int)c->row_count,
+                                             c->aux_stream));
             }
-            HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
-            c->early_groups = n_groups - 1;
-            c->early_rows = rows_early;
-        } else {
-            TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone: rocprofv3's time for it
-            HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_red[(size_t)p], c->aux_stream));
+            if (p + 2 < K)
+                if (int rc = diag_launch(p + 2))
+                    return rc;
         }
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->pending = &plan.parts.back();
         for (int s = 0; s < c->n_splits; ++s)
             if ((s >= first && s < first + count) != complement)
                 c->split_done[(size_t)s] = 1;
         c->sym_reduced = false;
         return NBODY_OK;
+    }
+    {
+        int rc = ensure_partials(c);
+        if (rc != NBODY_OK)
+            return rc;
     }
     ForceArgs a;
     a.split_mass = c->split_mass;

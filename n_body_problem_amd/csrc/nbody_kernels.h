@@ -87,9 +87,10 @@ size_t symmetric_lds_bytes(int split_len);
 hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
                                int split_lo, int group_splits, int group_lo, int group_count, hipStream_t stream);
 // rowsum[g][b] = sum over C in group g (ascending, where the tile (B(b), C) exists, and the diagonal C == B(b)) of
-// P_row[d(B, C)][b] for the own rows [b_lo, b_hi); rowsum is [groups][row_count] float4.
+// P_row[d(B, C)][b] for the rows [row_lo, row_lo + row_count) that row_partials ([n_splits/2+1][row_count]) holds; rowsum
+// points at the first of them in a [groups][out_stride] float4 array.
 hipError_t launch_sym_rowsum(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count, int split_len, int n_splits,
-                             int group_splits, int b_lo, int b_hi, hipStream_t stream);
+                             int group_splits, int out_stride, hipStream_t stream);
 // acc[b] = sum over the groups g (ascending) of ( rowsum[g][b] + colparts[g][b] ): the same association for any number of ranks.
 hipError_t launch_sym_combine(const float4 *rowsum, const float4 *colparts, float4 *acc, int row_lo, int row_count, int n_total,
                               int n_groups, hipStream_t stream);

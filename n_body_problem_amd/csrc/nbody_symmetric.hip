@@ -765,14 +765,15 @@ __global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float3 *col_p
 }
 
 // rowsum[g][b] = sum over the column splits C of group g (ascending, where the tile (B(b), C) exists, and the diagonal
-// C == B(b)) of P_row[d(B, C)][b], for the own rows [b_lo, b_hi): the row-side half of the canonical summation.  It needs
-// only the tiles whose row side is b's split, so the rows of the groups a launch has finished can be summed while later
-// tiles still run.
+// C == B(b)) of P_row[d(B, C)][b], for the rows [row_lo, row_lo + row_count) whose [n_splits/2+1][row_count] array
+// row_partials is: the row-side half of the canonical summation.  It needs only the tiles whose row side is b's split, so
+// the rows of the groups a launch has finished can be summed while later tiles still run.  rowsum (already offset to the
+// first of these rows) has out_stride entries per group.
 __global__ __launch_bounds__(kTile) void sym_rowsum_kernel(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count,
-                                                           int split_len, int n_splits, int group_splits, int b_lo, int b_hi)
+                                                           int split_len, int n_splits, int group_splits, int out_stride)
 {
-    const int b = b_lo + blockIdx.x * kTile + threadIdx.x;
-    if (b >= b_hi)
+    const int b = blockIdx.x * kTile + threadIdx.x;
+    if (b >= row_count)
         return;
     const int B = (row_lo + b) / split_len;
     for (int g = 0; g * group_splits < n_splits; ++g) {
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(kTile) void sym_rowsum_kernel(const float3 *row_par
                 sy += v.y;
                 sz += v.z;
             }
-        rowsum[(size_t)g * row_count + b] = make_float4(sx, sy, sz, 0.f);
+        rowsum[(size_t)g * out_stride + b] = make_float4(sx, sy, sz, 0.f);
     }
 }
 
@@ -819,12 +820,12 @@ hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int
 }
 
 hipError_t launch_sym_rowsum(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count, int split_len, int n_splits,
-                             int group_splits, int b_lo, int b_hi, hipStream_t stream)
+                             int group_splits, int out_stride, hipStream_t stream)
 {
-    if (b_hi <= b_lo)
+    if (row_count <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sym_rowsum_kernel, dim3((b_hi - b_lo + kTile - 1) / kTile), dim3(kTile), 0, stream, row_partials, rowsum,
-                       row_lo, row_count, split_len, n_splits, group_splits, b_lo, b_hi);
+    hipLaunchKernelGGL(sym_rowsum_kernel, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, row_partials, rowsum,
+                       row_lo, row_count, split_len, n_splits, group_splits, out_stride);
     return hipGetLastError();
 }
 

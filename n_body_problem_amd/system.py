@@ -277,6 +277,15 @@ class NBodySystem:
         result is bit-identical either way)."""
         check(self._lib.nbody_set_early_summation(self._ctx, 1 if on else 0), self._ctx)
 
+    def set_summation_parts(self, parts: int) -> None:
+        """Pair-once mode on one context: 1, 2, 4 or 8 launches of whole row groups, each part's sums formed beside the next
+        part's tiles; 4 and 8 keep only two parts' partial sums in memory.  0 = the default.  Bit-identical throughout."""
+        check(self._lib.nbody_set_summation_parts(self._ctx, int(parts)), self._ctx)
+
+    def partial_sum_bytes(self) -> int:
+        """Bytes of partial-sum arrays allocated so far (the first force call allocates them)."""
+        return int(self._lib.nbody_partial_sum_bytes(self._ctx))
+
     def device_info(self) -> dict:
         out = (ctypes.c_int64 * 4)()
         name = ctypes.create_string_buffer(128)

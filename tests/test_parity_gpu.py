@@ -476,30 +476,67 @@ def test_graph_replay_of_a_step_gives_the_same_bits(nb, mode, integrator):
 
 
 @pytest.mark.parametrize("integrator", ["kick_drift", "kdk"])
-def test_early_summation_changes_no_bit(nb, integrator):
-    """Pair-once mode, one context, a system large enough for two tile launches: the sums of the finished row groups are
-    formed on the auxiliary stream while the last group's tiles run.  The association is by groups either way, so the state
-    must equal the single-launch path bit for bit (also against two shards, which never sum early)."""
+def test_summation_parts_change_no_bit(nb, integrator):
+    """Pair-once mode, one context, a system large enough for several tile launches: the row groups go in 1, 2, 4 or 8
+    launches, each part's sums formed on the auxiliary stream beside the next part's tiles; with 4 and 8 parts the partial
+    sums live in two slots used in turn (a fraction of the memory).  The association is by groups in every case, so the state
+    must be the same bit for bit (also against two shards, which always take one part)."""
     from n_body_problem_amd.multi import MultiGpuSystem
     n, steps = 1 << 18, 3                       # 256 splits of 1024: 32 640 tiles
     pos, vel = nb.plummer(n, seed=19)
     pos[: n // 3, 3] *= 2.0                     # two mass species: both inner loops run
-    out = {}
-    for early in (True, False):
+    out, held = {}, {}
+    for parts in (1, 2, 4, 8, 0):
         with nb.NBodySystem(n, split_len=1024) as s:
             s.set_force_mode("pair_once")
             s.set_integrator(integrator)
-            s.set_early_summation(early)
+            s.set_summation_parts(parts)
             s.setParticlesPosition(pos)
             s.setParticlesVelocity(vel)
             s.step_n(steps, 1e-3, 1e-3)
-            out[early] = s.download()
-    assert np.array_equal(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])
+            out[parts] = s.download()
+            held[parts] = s.partial_sum_bytes()
+    for parts in (2, 4, 8, 0):
+        assert np.array_equal(out[parts][0], out[1][0]) and np.array_equal(out[parts][1], out[1][1]), parts
+    whole = 12 * n * n // 1024                  # n^2 / split_len entries of 12 bytes
+    assert abs(held[1] - whole) < whole // 100 and abs(held[2] - whole) < whole // 100
+    assert held[4] <= whole // 2 * 1.01 and held[8] <= whole // 4 * 1.01, held   # + the diagonal tiles' slot
     with MultiGpuSystem(n, devices=[0, 0], force_mode="pair_once", integrator=integrator, transport="peer_copy") as m:
         m.set_state(pos, vel)
         m.step_n(steps, 1e-3, 1e-3)
         p, v = m.download()
-    assert np.array_equal(p, out[True][0]) and np.array_equal(v, out[True][1])
+    assert np.array_equal(p, out[1][0]) and np.array_equal(v, out[1][1])
+
+
+def test_summation_parts_api(nb):
+    """Changing the number of parts between steps is allowed (the plans are rebuilt); a column-range call after an all-columns
+    call in several parts is refused (the earlier parts are already summed); bad values are refused."""
+    n = 1 << 18
+    pos, vel = nb.plummer(n, seed=23)
+    with nb.NBodySystem(n, split_len=1024) as s:
+        s.set_force_mode("pair_once")
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        with pytest.raises(nb.NBodyError):
+            s.set_summation_parts(3)
+        s.set_summation_parts(8)
+        s.step(1e-3, 1e-3)
+        s.set_summation_parts(2)
+        s.step(1e-3, 1e-3)
+        s.set_early_summation(False)
+        s.step(1e-3, 1e-3)
+        got = s.download()
+        s.set_summation_parts(4)
+        s.forces(0, n, 1e-3)
+        with pytest.raises(nb.NBodyError):
+            s.forces(0, 1024, 1e-3)
+    with nb.NBodySystem(n, split_len=1024) as s:
+        s.set_force_mode("pair_once")
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(3, 1e-3, 1e-3)
+        want = s.download()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
 # ---- diagnostics -----------------------------------------------------------------------------------

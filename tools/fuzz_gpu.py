@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Seeded random configurations through both force modes on one GPU: pair-once vs one-sided vs the fp64 oracle, two
-row-sharing contexts (hand-copied exchange) vs one, and 2-8 shards with the library-owned exchange (nbody_multi_*, peer
+row-sharing contexts (hand-copied exchange) vs one, 1/2/4/8 summation parts, and 2-8 shards with the library-owned exchange (nbody_multi_*, peer
 copies) vs one context on the padded system.  Mass patterns: random, equal, a few species in index order (some splits
 take the equal-mass loop, some do not), massless and very heavy bodies.  python tools/fuzz_gpu.py [cases] [seed]"""
 import os
@@ -8,17 +8,20 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("NBODY_SYM_PARTS_MIN_TILES", "0")    # summation parts (several tile launches) at every size
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import n_body_problem_amd as nb  # noqa: E402
 import oracle  # noqa: E402  (this is a test tool)
 
 
-def accel(pos, eps, mode, L, shards=1):
+def accel(pos, eps, mode, L, shards=1, parts=1):
     n = pos.shape[0]
     zero = np.zeros_like(pos)
     if shards == 1:
         with nb.NBodySystem(n, split_len=L) as s:
             s.set_force_mode(mode)
+            s.set_summation_parts(parts)
             s.setParticlesPosition(pos)
             s.setParticlesVelocity(zero)
             s.step(1.0, eps)
@@ -80,6 +83,8 @@ def main():
             pos[k, :3] = pos[(k + rng.integers(1, n)) % n, :3]
         one = accel(pos, eps, "one_sided", L)
         pair = accel(pos, eps, "pair_once", L)
+        for parts in (2, 4, 8):                                  # the row groups in several launches: the same bits
+            assert np.array_equal(accel(pos, eps, "pair_once", L, parts=parts), pair), (case, n, L, eps, parts)
         assert np.isfinite(one).all() and np.isfinite(pair).all(), (case, n, L, eps)
         scale = np.linalg.norm(one) + 1e-30
         d = np.linalg.norm(pair - one) / scale
