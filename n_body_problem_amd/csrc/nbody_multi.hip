@@ -730,15 +730,78 @@ static int forces_all_columns(nbody_multi *m, float softening)
     return NBODY_OK;
 }
 
-// Pair-once mode: the column-side sums of every rank's groups, for every body, gathered from every rank.
+// Pair-once mode: rank q's update needs colparts[g][rows of q] for every group g, and rank r holds colparts[g][every body]
+// for its own groups g.  So r hands q the rows-of-q segment of each of its 8 / P groups and receives q's in return:
+// (P - 1) x 8 / P segments of C x 16 B per rank (14 MiB at N = 2^20, P = 8) -- an eighth of gathering whole group slices,
+// all point to point, which is what xGMI is.  The segments land where sym_combine_kernel reads them.
+static int exchange_column_sums(nbody_multi *m)
+{
+    const size_t nl = m->ranks.size();
+    const int P = m->world, per_rank = NBODY_SYM_GROUPS / P;
+    const size_t seg = 4 * (size_t)m->chunk, group = 4 * (size_t)m->n_padded;  // floats
+    Channel &ch = m->ch_col;
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(ch.ready[i], r.compute));  // own groups summed; the previous step's reader is done
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        if (rccl(m)) {  // a segment is written once its owner has posted the receive, behind its own `ready`
+            MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[i], 0));
+        } else {        // peer copies write into the others' buffers: wait until they have stopped reading them
+            for (size_t j = 0; j < nl; ++j)
+                MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[j], 0));
+        }
+    }
+    if (rccl(m)) {
+        MNCCL(m, ncclGroupStart());
+        for (Rank &r : m->ranks)
+            for (int q = 0; q < P; ++q) {
+                if (q == r.rank)
+                    continue;
+                for (int k = 0; k < per_rank; ++k) {
+                    ncclResult_t e = ncclSend(r.colparts + (size_t)(r.rank * per_rank + k) * group + (size_t)q * seg, seg, ncclFloat,
+                                              q, r.nccl, r.comm);
+                    if (e == ncclSuccess)
+                        e = ncclRecv(r.colparts + (size_t)(q * per_rank + k) * group + (size_t)r.rank * seg, seg, ncclFloat, q,
+                                     r.nccl, r.comm);
+                    if (e != ncclSuccess) {
+                        (void)ncclGroupEnd();
+                        return mfail(m, NBODY_ERR_DEVICE, std::string("ncclSend/ncclRecv: RCCL: ") + ncclGetErrorString(e));
+                    }
+                }
+            }
+        MNCCL(m, ncclGroupEnd());
+    } else {
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            for (Rank &d : m->ranks) {
+                if (d.rank == r.rank)
+                    continue;
+                for (int k = 0; k < per_rank; ++k) {
+                    const size_t at = (size_t)(r.rank * per_rank + k) * group + (size_t)d.rank * seg;
+                    MHIP(m, hipMemcpyPeerAsync(d.colparts + at, d.device, r.colparts + at, r.device, seg * sizeof(float), r.comm));
+                }
+            }
+        }
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(ch.done[i], r.comm));
+    }
+    return NBODY_OK;
+}
+
 static int sum_forces(nbody_multi *m)
 {
     if (!pair_once(m) || m->world == 1)
         return NBODY_OK;  // one context: nbody_update / nbody_kdk_* run the reduction themselves
     for (Rank &r : m->ranks)
         MCTX(m, r, nbody_sym_reduce(r.ctx));
-    const size_t slice = 4 * (size_t)(NBODY_SYM_GROUPS / m->world) * (size_t)m->n_padded;
-    int rc = start_allgather(m, m->ch_col, &Rank::colparts, slice);
+    int rc = exchange_column_sums(m);
     for (size_t i = 0; rc == NBODY_OK && i < m->ranks.size(); ++i)
         rc = wait_allgather(m, m->ch_col, i, m->ranks[i].compute);
     return rc;

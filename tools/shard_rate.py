@@ -1,9 +1,14 @@
 """One rank of P's share of a force pass, timed on one GPU (the other ranks' work is simply not done):
 python tools/shard_rate.py [--bodies N] [--world 8] [--rank 3] [--mode pair_once] [--split-len L ...]"""
 import argparse
+import os
+import sys
+
 import torch
-import n_body_problem_amd as nb
-from n_body_problem_amd.sharded import pair_once_geometry, shard_geometry
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import n_body_problem_amd as nb  # noqa: E402
+from n_body_problem_amd.sharded import pair_once_geometry, shard_geometry  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--bodies", type=int, default=1 << 20)
