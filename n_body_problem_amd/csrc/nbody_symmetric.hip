@@ -142,7 +142,7 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
 // Lane l meets columns (l + s) and (l + s + 32) mod 64 at step s = 0..31, the pair sharing every v_pk_{add,mul,fma}_f32:
 // 7 packed instructions + 1 transcendental per pair evaluation instead of 14 + 1 (the cycles are the same, 4 per packed
 // instruction; what halves is the number of instructions issued -- the kernel sits on the power limit).  The group is
-// staged as three arrays x[96], y[96], z[96] (the first 32 columns repeated behind the 64, so column + 32 needs no wrap)
+// staged as three arrays x[128], y[128], z[128] (the 64 columns twice, so neither the step nor column + 32 needs a wrap)
 // and read with ds_read2_b32; both columns' sums travel one lane per step (six permutes for eight pairs); the row sums are
 // kept per column of the pair and added when the pass ends.  Two batches of 2 rows x 2 columns per step keep the batch of
 // four v_rsq_f32 of the other loops.  64-bit operands in even pairs; pair classes ((reg / 2) mod 2) of src0 and src1 differ:
@@ -150,7 +150,7 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
 //   rows         v[12:27] as above: (x, y) pairs class 0, (z, m) pairs class 1
 //   temps A / B  R = v[28:29] / v[32:33] (0)   DX, DY, DZ = v[30:31], v[34:35], v[38:39] / v[42:43], v[46:47], v[50:51] (1)
 //   Q = v[54:55] (1)     column sums CX, CY, CZ = v[36:37], v[40:41], v[44:45]      row sums v[56:79]: row k, component c at
-//   v[56 + 6k + 2c : 57 + 6k + 2c]          v0 / v1 / v10 / v52 / v53: address, offset, base, mask (255), permute source
+//   v[56 + 6k + 2c : 57 + 6k + 2c]          v0 / v1 / v53: address of x and y, address of z (and m), permute source
 #define S2_NEG " neg_lo:[0,1] neg_hi:[0,1]\n\t"
 #define S2_PRE(RXY, RZM, DX, DY, DZ, R)                                                                          \
     "v_pk_add_f32 " DX ", v[2:3], " RXY " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                      \
@@ -168,19 +168,15 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
 #define S2_ROTATE                                                                                                \
     "ds_bpermute_b32 v36, v53, v36\n\tds_bpermute_b32 v37, v53, v37\n\tds_bpermute_b32 v40, v53, v40\n\t"            \
     "ds_bpermute_b32 v41, v53, v41\n\tds_bpermute_b32 v44, v53, v44\n\tds_bpermute_b32 v45, v53, v45\n\t"
-#define S2_READ                                                                                                  \
-    "ds_read2_b32 v[2:3], v0 offset1:32\n\tds_read2_b32 v[6:7], v0 offset0:96 offset1:128\n\t"                       \
-    "ds_read2_b32 v[4:5], v0 offset0:192 offset1:224\n\t"
-#define S2_GROUP_LOOP                                                                                            \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
-    "v_and_or_b32 v0, v1, v52, v10\n\t"                                                                          \
-    S2_READ                                                                                                      \
-    S2_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
-    NB_SYM_PRIO_PRE                                                                                              \
-    "s_mov_b32 %[cnt], 32\n"                                                                                     \
-    "1:\n\t"                                                                                                     \
-    "v_add_u32_e32 v1, 4, v1\n\t"                                                                                \
-    "v_and_or_b32 v0, v1, v52, v10\n\t"                                                                          \
+// The group is staged as x[128], y[128], z[128] (, m[128]): the 64 columns twice, so lane l reads columns l + s and
+// l + s + 32 at dword l + s (+ 32) without wrapping and the step number is an immediate offset: four steps per loop
+// iteration, the two addresses (v0: x at +0, y at +128 dwords; v1 = v0 + 1024 bytes: z at +0, m at +128) advance once per
+// iteration instead of an add and a mask per step.
+#define S2_READ(X0, X1, Y0, Y1)                                                                                  \
+    "ds_read2_b32 v[2:3], v0 offset0:" X0 " offset1:" X1 "\n\tds_read2_b32 v[6:7], v0 offset0:" Y0 " offset1:" Y1 "\n\t" \
+    "ds_read2_b32 v[4:5], v1 offset0:" X0 " offset1:" X1 "\n\t"
+#define S2_ADVANCE "v_add_u32_e32 v0, 16, v0\n\tv_add_u32_e32 v1, 16, v1\n\t"
+#define S2_STEP(NEXT)                                                                                            \
     "s_waitcnt lgkmcnt(6)\n\t" /* the column pair has arrived; the six permutes behind it may be in flight */    \
     S2_PRE("v[12:13]", "v[14:15]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
     S2_PRE("v[16:17]", "v[18:19]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
@@ -193,14 +189,25 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     NB_SYM_PRIO_PRE                                                                                              \
     S2_PRE("v[20:21]", "v[22:23]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
     S2_PRE("v[24:25]", "v[26:27]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
-    S2_READ /* the next step's column pair: the current one has been consumed by the four PRE blocks */          \
+    NEXT /* the next step's column pair: the current one has been consumed by the four PRE blocks */             \
     "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
     NB_SYM_GAP                                                                                                   \
     NB_SYM_PRIO_POST                                                                                             \
     S2_POST("v[68:69]", "v[70:71]", "v[72:73]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                  \
     S2_POST("v[74:75]", "v[76:77]", "v[78:79]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                  \
     NB_SYM_PRIO_PRE                                                                                              \
-    S2_ROTATE                                                                                                    \
+    S2_ROTATE
+#define S2_GROUP_LOOP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    S2_READ("0", "32", "128", "160")                                                                             \
+    S2_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 8\n"                                                                                      \
+    "1:\n\t"                                                                                                     \
+    S2_STEP(S2_READ("1", "33", "129", "161"))                                                                    \
+    S2_STEP(S2_READ("2", "34", "130", "162"))                                                                    \
+    S2_STEP(S2_READ("3", "35", "131", "163"))                                                                    \
+    S2_STEP(S2_ADVANCE S2_READ("0", "32", "128", "160"))                                                         \
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
@@ -208,9 +215,9 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     "s_waitcnt lgkmcnt(0)\n"
 
 // ---- the same two-columns-per-step loop for tiles with arbitrary masses: 8 packed instructions + 1 transcendental per pair
-// (one-column loop: 16 + 1).  The group's masses are staged as a fourth array m[96] behind x, y, z and read at the END of
+// (one-column loop: 16 + 1).  The group's masses are staged as a fourth array m[128] behind x, y, z and read at the END of
 // a step (the positions are consumed by the PRE blocks, the masses by the POST blocks of both batches).
-//   v9 = the wave's stage base   PM = v[10:11] (1) the pair's masses   v48 = address of the masses   S = v[80:81] (0) m_col * inv^3
+//   PM = v[10:11] (1) the pair's masses, read through v1 (z at +0, m at +128 dwords)   S = v[80:81] (0) m_col * inv^3
 #define S3_POST(RZM, AX, AY, AZ, DX, DY, DZ, R)                                                                  \
     "v_pk_mul_f32 v[54:55], " R ", " R "\n\tv_pk_mul_f32 " R ", " R ", v[54:55]\n\t"                                 \
     "v_pk_mul_f32 v[80:81], v[10:11], " R "\n\t"                                                                   \
@@ -219,19 +226,8 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     "v_pk_fma_f32 " AZ ", " DZ ", v[80:81], " AZ "\n\t"                                                              \
     "v_pk_fma_f32 v[36:37], " DX ", " R ", v[36:37]\n\tv_pk_fma_f32 v[40:41], " DY ", " R ", v[40:41]\n\t"             \
     "v_pk_fma_f32 v[44:45], " DZ ", " R ", v[44:45]\n\t"
-#define S3_GROUP_LOOP                                                                                            \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
-    "v_and_or_b32 v0, v1, v52, v9\n\t"                                                                           \
-    "v_add_u32_e32 v48, 1152, v0\n\t"                                                                            \
-    S2_READ                                                                                                      \
-    "ds_read2_b32 v[10:11], v48 offset1:32\n\t"                                                                  \
-    S2_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
-    NB_SYM_PRIO_PRE                                                                                              \
-    "s_mov_b32 %[cnt], 32\n"                                                                                     \
-    "1:\n\t"                                                                                                     \
-    "v_add_u32_e32 v1, 4, v1\n\t"                                                                                \
-    "v_and_or_b32 v0, v1, v52, v9\n\t"                                                                           \
-    "v_add_u32_e32 v48, 1152, v0\n\t"                                                                            \
+#define S3_MASSES(M0, M1) "ds_read2_b32 v[10:11], v1 offset0:" M0 " offset1:" M1 "\n\t"
+#define S3_STEP(NEXT, NEXT_MASSES)                                                                               \
     "s_waitcnt lgkmcnt(7)\n\t" /* the positions of the column pair have arrived (masses and permutes may be in flight) */ \
     S2_PRE("v[12:13]", "v[14:15]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
     S2_PRE("v[16:17]", "v[18:19]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
@@ -244,15 +240,27 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     NB_SYM_PRIO_PRE                                                                                              \
     S2_PRE("v[20:21]", "v[22:23]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
     S2_PRE("v[24:25]", "v[26:27]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
-    S2_READ /* the next step's positions */                                                                      \
+    NEXT /* the next step's positions */                                                                         \
     "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
     NB_SYM_GAP                                                                                                   \
     NB_SYM_PRIO_POST                                                                                             \
     S3_POST("v[22:23]", "v[68:69]", "v[70:71]", "v[72:73]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")      \
     S3_POST("v[26:27]", "v[74:75]", "v[76:77]", "v[78:79]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")      \
     NB_SYM_PRIO_PRE                                                                                              \
-    "ds_read2_b32 v[10:11], v48 offset1:32\n\t" /* the next step's masses */                                     \
-    S2_ROTATE                                                                                                    \
+    NEXT_MASSES /* the next step's masses */                                                                     \
+    S2_ROTATE
+#define S3_GROUP_LOOP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    S2_READ("0", "32", "128", "160")                                                                             \
+    S3_MASSES("128", "160")                                                                                      \
+    S2_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 8\n"                                                                                      \
+    "1:\n\t"                                                                                                     \
+    S3_STEP(S2_READ("1", "33", "129", "161"), S3_MASSES("129", "161"))                                           \
+    S3_STEP(S2_READ("2", "34", "130", "162"), S3_MASSES("130", "162"))                                           \
+    S3_STEP(S2_READ("3", "35", "131", "163"), S3_MASSES("131", "163"))                                           \
+    S3_STEP(S2_ADVANCE S2_READ("0", "32", "128", "160"), S3_MASSES("128", "160"))                                \
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
@@ -354,20 +362,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
             ra[k][0] = ra[k][1] = ra[k][2] = nb_f2{0.f, 0.f};
         for (int g = 0; g < G; ++g) {
             const int cg = sym_group(g, wave, spacing, G);
-            if constexpr (PACKED) {  // the group as x[96], y[96], z[96] (, m[96]): columns 0..31 repeated behind the 64
+            if constexpr (PACKED) {  // the group as x[128], y[128], z[128] (, m[128]): the 64 columns twice
                 float *st = reinterpret_cast<float *>(lds.stage);
-                st[lane] = cnext.x;
-                st[96 + lane] = cnext.y;
-                st[192 + lane] = cnext.z;
+                st[lane] = st[64 + lane] = cnext.x;
+                st[128 + lane] = st[192 + lane] = cnext.y;
+                st[256 + lane] = st[320 + lane] = cnext.z;
                 if (VARIANT == 3)
-                    st[288 + lane] = cnext.w;
-                if (lane < 32) {
-                    st[64 + lane] = cnext.x;
-                    st[160 + lane] = cnext.y;
-                    st[256 + lane] = cnext.z;
-                    if (VARIANT == 3)
-                        st[352 + lane] = cnext.w;
-                }
+                    st[384 + lane] = st[448 + lane] = cnext.w;
             } else {
                 lds.stage[lane] = cnext;
             }
@@ -379,18 +380,18 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
             }
             if constexpr (VARIANT == 3) {
                 nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
-                unsigned off = 4u * (unsigned)lane, addr = 0, cnt;
-                const unsigned base = (unsigned)(size_t)lds.stage, mask = 255u, next_lane = 4u * ((lane + 1) & 63);
+                unsigned addr = (unsigned)(size_t)lds.stage + 4u * (unsigned)lane, addr_zm = addr + 1024u, cnt;
+                const unsigned next_lane = 4u * ((lane + 1) & 63);
                 const float eps2 = a.eps2;
                 asm volatile(S3_GROUP_LOOP
                              : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
                                "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
                                "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
-                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_zm), "+{v0}"(addr), [cnt] "=&s"(cnt)
                              : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
-                               "{v8}"(eps2), "{v9}"(base), "{v52}"(mask), "{v53}"(next_lane)
+                               "{v8}"(eps2), "{v53}"(next_lane)
                              : "v2", "v3", "v4", "v5", "v6", "v7", "v10", "v11", "v28", "v29", "v30", "v31", "v32", "v33", "v34",
-                               "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v48", "v50", "v51", "v54", "v55", "v80", "v81",
+                               "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v80", "v81",
                                "scc", "memory");
                 const int ca = cg * 64 + ((lane + 32) & 63), cb = cg * 64 + lane;  // as in the equal-mass loop below
                 lds.sx[ca] -= cx.x;
@@ -405,16 +406,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
             }
             if constexpr (VARIANT == 2) {
                 nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
-                unsigned off = 4u * (unsigned)lane, addr = 0, cnt;
-                const unsigned base = (unsigned)(size_t)lds.stage, mask = 255u, next_lane = 4u * ((lane + 1) & 63);
+                unsigned addr = (unsigned)(size_t)lds.stage + 4u * (unsigned)lane, addr_z = addr + 1024u, cnt;
+                const unsigned next_lane = 4u * ((lane + 1) & 63);
                 const nb_f2 epsv = {a.eps2, 0.f};
                 asm volatile(S2_GROUP_LOOP
                              : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
                                "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
                                "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
-                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), [cnt] "=&s"(cnt)
                              : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
-                               "{v[8:9]}"(epsv), "{v10}"(base), "{v52}"(mask), "{v53}"(next_lane)
+                               "{v[8:9]}"(epsv), "{v53}"(next_lane)
                              : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
                                "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory");
                 // after 32 steps and rotations the lane holds the first-half sum of column lane + 32 and the second-half

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--softening", type=float, default=1e-3)
     ap.add_argument("--split-len", type=int, default=0)
     ap.add_argument("--symmetric", action="store_true", help="time the experimental pair-once kernel (rpl is ignored)")
+    ap.add_argument("--general-masses", action="store_true", help="equal-mass inner loops off: every split down the general path")
     args = ap.parse_args()
 
     import torch
@@ -58,6 +59,8 @@ def main():
         lib.nbody_timing_enable(ctx, 1)
         if args.symmetric:
             assert lib.nbody_set_force_mode(ctx, 1) == 0, lib.nbody_last_error(ctx)
+        if args.general_masses:
+            assert lib.nbody_set_equal_mass_path(ctx, 0) == 0
         for rpl in [int(x) for x in args.rpl.split(",")]:
             variants.append((f"{name}/rpl{rpl}", lib, ctx, rpl))
 
