@@ -907,7 +907,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         // equal-mass tiles run the packed two-columns-per-step loop (163 against 170 ms per N = 2^20 pass); NBODY_SYM_PACKED=0
         // keeps the one-column loop for A/B measurement
         static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 1;
-        sa.packed = packed_env;
+        sa.packed = c->rows_per_lane == 8 ? 2 : c->rows_per_lane == 4 ? 1 : packed_env;  // nbody_set_rows_per_lane: A/B in one process
         auto part_args = [&](const nbody_ctx::SymPart &p) {
             sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;
             sa.col_partials = c->col_partials + p.col_off;

@@ -165,19 +165,29 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     "v_pk_fma_f32 " AZ ", " DZ ", " R ", " AZ "\n\t"                                                                 \
     "v_pk_fma_f32 v[36:37], " DX ", " R ", v[36:37]\n\tv_pk_fma_f32 v[40:41], " DY ", " R ", v[40:41]\n\t"             \
     "v_pk_fma_f32 v[44:45], " DZ ", " R ", v[44:45]\n\t"
+#ifdef NB_EXP_NOROT  /* timing experiment only (wrong sums): what the six permutes of a step cost */
+#define S2_ROTATE ""
+#define S2_WAIT_TOP "s_waitcnt lgkmcnt(0)\n\t"
+#else
 #define S2_ROTATE                                                                                                \
     "ds_bpermute_b32 v36, v53, v36\n\tds_bpermute_b32 v37, v53, v37\n\tds_bpermute_b32 v40, v53, v40\n\t"            \
     "ds_bpermute_b32 v41, v53, v41\n\tds_bpermute_b32 v44, v53, v44\n\tds_bpermute_b32 v45, v53, v45\n\t"
+#define S2_WAIT_TOP "s_waitcnt lgkmcnt(6)\n\t" /* the column pair has arrived; the six permutes behind it may be in flight */
+#endif
 // The group is staged as x[128], y[128], z[128] (, m[128]): the 64 columns twice, so lane l reads columns l + s and
 // l + s + 32 at dword l + s (+ 32) without wrapping and the step number is an immediate offset: four steps per loop
 // iteration, the two addresses (v0: x at +0, y at +128 dwords; v1 = v0 + 1024 bytes: z at +0, m at +128) advance once per
 // iteration instead of an add and a mask per step.
+#ifdef NB_EXP_NOREAD  /* timing experiment only (wrong sums): what the three reads of a step cost */
+#define S2_READ(X0, X1, Y0, Y1) ""
+#else
 #define S2_READ(X0, X1, Y0, Y1)                                                                                  \
     "ds_read2_b32 v[2:3], v0 offset0:" X0 " offset1:" X1 "\n\tds_read2_b32 v[6:7], v0 offset0:" Y0 " offset1:" Y1 "\n\t" \
     "ds_read2_b32 v[4:5], v1 offset0:" X0 " offset1:" X1 "\n\t"
+#endif
 #define S2_ADVANCE "v_add_u32_e32 v0, 16, v0\n\tv_add_u32_e32 v1, 16, v1\n\t"
 #define S2_STEP(NEXT)                                                                                            \
-    "s_waitcnt lgkmcnt(6)\n\t" /* the column pair has arrived; the six permutes behind it may be in flight */    \
+    S2_WAIT_TOP                                                                                                  \
     S2_PRE("v[12:13]", "v[14:15]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")                               \
     S2_PRE("v[16:17]", "v[18:19]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")                               \
     "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
@@ -208,6 +218,78 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     S2_STEP(S2_READ("2", "34", "130", "162"))                                                                    \
     S2_STEP(S2_READ("3", "35", "131", "163"))                                                                    \
     S2_STEP(S2_ADVANCE S2_READ("0", "32", "128", "160"))                                                         \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"
+
+// ---- equal-mass tiles, EIGHT rows per lane (SymArgs::packed == 2): the same two-columns-per-step loop with twice the rows
+// behind every column pair, so the LDS traffic of a step (three reads, six permutes: 8 % of the pass, measured by leaving
+// them out, profiles/r02_ab_lds_cost.txt) serves 16 pair evaluations instead of 8.  A wave covers 512 rows (two waves per
+// 1024-body split), 4 waves per SIMD instead of 5.  Rows as (x, y) pairs (class 0) and (z, z') pairs of two rows (class 1):
+//   rows 0..3   v[12:13] v[16:17] v[20:21] v[24:25]   rows 4..7   v[48:49] v[52:53] v[56:57] v[60:61]
+//   (z0, z1) v[14:15]   (z2, z3) v[18:19]   (z4, z5) v[22:23]   (z6, z7) v[26:27]
+//   row sums: row k, component c at v[64 + 6k + 2c : 65 + 6k + 2c]      v10: permute source      temps, column pair, column
+//   sums, eps^2, addresses as in the four-row loop.  Four batches of 2 rows x 2 columns per step.
+#define S8_ZLO " op_sel:[0,0] op_sel_hi:[1,0]"
+#define S8_ZHI " op_sel:[0,1] op_sel_hi:[1,1]"
+#define S8_PRE(...) S8_PRE_I(__VA_ARGS__) /* S8_TA / S8_TB expand to four arguments */
+#define S8_POST(...) S2_POST(__VA_ARGS__)
+#define S8_PRE_I(RXY, RZZ, ZSEL, DX, DY, DZ, R)                                                                  \
+    "v_pk_add_f32 " DX ", v[2:3], " RXY " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                      \
+    "v_pk_add_f32 " DY ", v[6:7], " RXY " op_sel:[0,1] op_sel_hi:[1,1]" S2_NEG                                      \
+    "v_pk_add_f32 " DZ ", v[4:5], " RZZ ZSEL S2_NEG                                                                 \
+    "v_pk_fma_f32 " R ", " DX ", " DX ", v[8:9] op_sel_hi:[1,1,0]\n\t"                                              \
+    "v_pk_fma_f32 " R ", " DY ", " DY ", " R "\n\t"                                                                  \
+    "v_pk_fma_f32 " R ", " DZ ", " DZ ", " R "\n\t"
+#define S8_ROTATE                                                                                                \
+    "ds_bpermute_b32 v36, v10, v36\n\tds_bpermute_b32 v37, v10, v37\n\tds_bpermute_b32 v40, v10, v40\n\t"            \
+    "ds_bpermute_b32 v41, v10, v41\n\tds_bpermute_b32 v44, v10, v44\n\tds_bpermute_b32 v45, v10, v45\n\t"
+#define S8_RSQ "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"
+#define S8_TA "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]"
+#define S8_TB "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]"
+#define S8_STEP(NEXT)                                                                                            \
+    "s_waitcnt lgkmcnt(6)\n\t" /* the column pair has arrived; the six permutes behind it may be in flight */    \
+    S8_PRE("v[12:13]", "v[14:15]", S8_ZLO, S8_TA)                                                                \
+    S8_PRE("v[16:17]", "v[14:15]", S8_ZHI, S8_TB)                                                                \
+    S8_RSQ NB_SYM_GAP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t" /* the column sums have arrived from the next lane */                             \
+    NB_SYM_PRIO_POST                                                                                             \
+    S8_POST("v[64:65]", "v[66:67]", "v[68:69]", S8_TA)                                                           \
+    S8_POST("v[70:71]", "v[72:73]", "v[74:75]", S8_TB)                                                           \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S8_PRE("v[20:21]", "v[18:19]", S8_ZLO, S8_TA)                                                                \
+    S8_PRE("v[24:25]", "v[18:19]", S8_ZHI, S8_TB)                                                                \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S8_POST("v[76:77]", "v[78:79]", "v[80:81]", S8_TA)                                                           \
+    S8_POST("v[82:83]", "v[84:85]", "v[86:87]", S8_TB)                                                           \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S8_PRE("v[48:49]", "v[22:23]", S8_ZLO, S8_TA)                                                                \
+    S8_PRE("v[52:53]", "v[22:23]", S8_ZHI, S8_TB)                                                                \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S8_POST("v[88:89]", "v[90:91]", "v[92:93]", S8_TA)                                                           \
+    S8_POST("v[94:95]", "v[96:97]", "v[98:99]", S8_TB)                                                           \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S8_PRE("v[56:57]", "v[26:27]", S8_ZLO, S8_TA)                                                                \
+    S8_PRE("v[60:61]", "v[26:27]", S8_ZHI, S8_TB)                                                                \
+    NEXT /* the next step's column pair: the current one has been consumed by the eight PRE blocks */            \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S8_POST("v[100:101]", "v[102:103]", "v[104:105]", S8_TA)                                                     \
+    S8_POST("v[106:107]", "v[108:109]", "v[110:111]", S8_TB)                                                     \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S8_ROTATE
+#define S8_GROUP_LOOP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    S2_READ("0", "32", "128", "160")                                                                             \
+    S8_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 8\n"                                                                                      \
+    "1:\n\t"                                                                                                     \
+    S8_STEP(S2_READ("1", "33", "129", "161"))                                                                    \
+    S8_STEP(S2_READ("2", "34", "130", "162"))                                                                    \
+    S8_STEP(S2_READ("3", "35", "131", "163"))                                                                    \
+    S8_STEP(S2_ADVANCE S2_READ("0", "32", "128", "160"))                                                         \
     "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
     "s_cbranch_scc1 1b\n\t"                                                                                      \
@@ -307,8 +389,9 @@ __device__ __forceinline__ int sym_group(int g, int wave, int spacing, int G)
 }
 
 // ---- off-diagonal tiles (I < J) ------------------------------------------------------------------------------
-template <int W, bool GUARD>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) void force_sym_kernel(SymArgs a)  // <= 96 VGPRs
+typedef float nb_f16 __attribute__((ext_vector_type(16)));
+template <int W, bool GUARD, bool ROWS8 = false>  // ROWS8: equal-mass tiles through the eight-rows-per-lane loop (<= 128 VGPRs)
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 4 : 5))) void force_sym_kernel(SymArgs a)  // <= 96 VGPRs
 {
     constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -480,7 +563,90 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5))) voi
         }
     }
     };
-    if (uniform && a.packed)
+    // equal-mass tiles, eight rows per lane (S8_GROUP_LOOP): a wave owns 512 rows of a pass
+    auto passes8 = [&]() {
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pass0 = 0; pass0 < L; pass0 += kSymThreads * 8) {
+            float4 p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = pass0 + (wave * 8 + k) * 64 + lane;
+                p[k] = zero4;
+                if (r < L && rowbase + r < row_hi)
+                    p[k] = a.pos[rowbase + r];
+            }
+            const nb_f16 rows = {p[0].x, p[0].y, p[0].z, p[1].z, p[1].x, p[1].y, p[2].z, p[3].z,
+                                 p[2].x, p[2].y, p[4].z, p[5].z, p[3].x, p[3].y, p[6].z, p[7].z};
+            const nb_f2 xy4 = {p[4].x, p[4].y}, xy5 = {p[5].x, p[5].y}, xy6 = {p[6].x, p[6].y}, xy7 = {p[7].x, p[7].y};
+            nb_f16 ra0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+            float4 cnext = zero4;  // the next group's column bodies, loaded a group ahead
+            {
+                const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + lane;
+                if (gc < a.n_total)
+                    cnext = a.pos[gc];
+            }
+            for (int g = 0; g < G; ++g) {
+                const int cg = sym_group(g, wave, spacing, G);
+                float *st = reinterpret_cast<float *>(lds.stage);
+                st[lane] = st[64 + lane] = cnext.x;
+                st[128 + lane] = st[192 + lane] = cnext.y;
+                st[256 + lane] = st[320 + lane] = cnext.z;
+                if (g + 1 < G) {
+                    const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + lane;
+                    cnext = zero4;
+                    if (gc < a.n_total)
+                        cnext = a.pos[gc];
+                }
+                nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
+                unsigned addr = (unsigned)(size_t)lds.stage + 4u * (unsigned)lane, addr_z = addr + 1024u, cnt;
+                const unsigned next_lane = 4u * ((lane + 1) & 63);
+                const nb_f2 epsv = {a.eps2, 0.f};
+                asm volatile(S8_GROUP_LOOP
+                             : "+{v[64:79]}"(ra0), "+{v[80:95]}"(ra1), "+{v[96:111]}"(ra2), "+{v[36:37]}"(cx), "+{v[40:41]}"(cy),
+                               "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                             : "{v[12:27]}"(rows), "{v[48:49]}"(xy4), "{v[52:53]}"(xy5), "{v[56:57]}"(xy6), "{v[60:61]}"(xy7),
+                               "{v[8:9]}"(epsv), "{v10}"(next_lane)
+                             : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
+                               "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory");
+                const int ca = cg * 64 + ((lane + 32) & 63), cb = cg * 64 + lane;  // as in the four-row loop
+                lds.sx[ca] -= cx.x;
+                lds.sy[ca] -= cy.x;
+                lds.sz[ca] -= cz.x;
+                lds.sx[cb] -= cx.y;
+                lds.sy[cb] -= cy.y;
+                lds.sz[cb] -= cz.y;
+                if ((g + 1) % spacing == 0)
+                    __syncthreads();
+            }
+            __syncthreads();
+            float3 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // row sums: P_row[d][row]
+            float sum[48];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sum[i] = ra0[i];
+                sum[16 + i] = ra1[i];
+                sum[32 + i] = ra2[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = pass0 + (wave * 8 + k) * 64 + lane;
+                if (r < L && rowbase + r < row_hi)
+                    out[rowbase + r - a.row_lo] = make_float3((sum[6 * k] + sum[6 * k + 1]) * row_scale,
+                                                              (sum[6 * k + 2] + sum[6 * k + 3]) * row_scale,
+                                                              (sum[6 * k + 4] + sum[6 * k + 5]) * row_scale);
+            }
+        }
+    };
+    bool done = false;
+    if constexpr (ROWS8 && !GUARD) {
+        if (uniform && L % (kSymThreads * 8) == 0) {
+            passes8();
+            done = true;
+        }
+    }
+    if (done)
+        ;
+    else if (uniform && a.packed)
         passes(std::integral_constant<int, 2>{});
     else if (uniform)
         passes(std::integral_constant<int, 1>{});
@@ -697,6 +863,11 @@ static hipError_t sym_launch(K kernel, int blocks, int waves, size_t lds, const 
     return hipGetLastError();
 }
 
+static size_t sym_lds_bytes_for(int waves, int split_len)
+{
+    return (size_t)waves * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + (size_t)waves * 64 * sizeof(float);
+}
+
 template <int W>
 static hipError_t sym_launch_tiles(const SymArgs &a, size_t lds, hipStream_t stream)
 {
@@ -719,6 +890,16 @@ static hipError_t sym_launch_diag(const SymArgs &a, size_t lds, hipStream_t stre
 
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
 {
+    // eight rows per lane for the equal-mass tiles (packed == 2): half the waves per split, 512 rows each
+    if (a.packed == 2 && !a.eps_pp && a.eps2 > 0.f && a.split_len % 512 == 0) {
+        const int w8 = a.split_len >= 2048 ? 4 : a.split_len / 512;
+        const size_t lds8 = sym_lds_bytes_for(w8, a.split_len);
+        switch (w8) {
+        case 4: return sym_launch(&force_sym_kernel<4, false, true>, a.n_tiles, 4, lds8, a, stream);
+        case 2: return sym_launch(&force_sym_kernel<2, false, true>, a.n_tiles, 2, lds8, a, stream);
+        default: return sym_launch(&force_sym_kernel<1, false, true>, a.n_tiles, 1, lds8, a, stream);
+        }
+    }
     const size_t lds = symmetric_lds_bytes(a.split_len);
     switch (sym_waves(a.split_len)) {
     case 4: return sym_launch_tiles<4>(a, lds, stream);
