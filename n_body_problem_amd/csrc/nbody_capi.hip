@@ -782,6 +782,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return NBODY_OK;
     const int first = (int)(col_lo / c->split_len);
     const int count = (int)((col_count + c->split_len - 1) / c->split_len);
+    if (complement ? count == c->n_splits : count == 0)
+        return NBODY_OK;  // no column selected
     if (c->force_mode == NBODY_FORCE_SYMMETRIC) {
         // this context's tiles with a column split in the range asked for, cut into parts (cached per range)
         const int S = c->n_splits, L = (int)c->split_len;
@@ -904,9 +906,10 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.eps2 = softening * softening;
         sa.eps_pp = c->eps_pp;
         sa.split_mass = c->split_mass;
-        // equal-mass tiles run the packed two-columns-per-step loop (163 against 170 ms per N = 2^20 pass); NBODY_SYM_PACKED=0
-        // keeps the one-column loop for A/B measurement
-        static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 1;
+        // 2 (default): packed two-columns-per-step loops, equal-mass tiles of splits of 1024 bodies and more with eight rows
+        // per lane (161 against 167 ms per N = 2^20 pass); NBODY_SYM_PACKED=1 keeps four rows per lane everywhere, 0 the
+        // one-column loops (170 ms) -- A/B measurement
+        static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 2;
         sa.packed = c->rows_per_lane == 8 ? 2 : c->rows_per_lane == 4 ? 1 : packed_env;  // nbody_set_rows_per_lane: A/B in one process
         auto part_args = [&](const nbody_ctx::SymPart &p) {
             sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;

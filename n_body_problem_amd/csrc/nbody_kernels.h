@@ -74,7 +74,8 @@ struct SymArgs {
     float eps2;
     const float *eps_pp;   // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
     const float *split_mass;  // [n_splits]: the one mass of a split's bodies, or NaN (launch_split_mass)
-    int packed;               // equal-mass tiles: the packed two-columns-per-step loop (default; 0: the one-column loop)
+    int packed;               // 0: one-column loops; 1: packed two-columns-per-step loops, four rows per lane; 2 (default): and
+                              // eight rows per lane on equal-mass tiles of splits >= 1024 bodies
 };
 // split_mass[s] for every split of the body set, from the masses now in pos (O(N); see split_mass_kernel)
 hipError_t launch_split_mass(const float4 *pos, float *split_mass, int n_total, int split_len, bool enabled, hipStream_t stream);
