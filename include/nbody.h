@@ -226,7 +226,7 @@ int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
  * groups either way).  parts = 1: one launch, then the whole summation.  2: every group but the last, then the last (one
  * extra launch tail; the partial-sum arrays hold the whole pass: n^2 / split_len 12-byte entries, 12.9 GB at N = 2^20).
  * 4, 8: equal parts whose arrays live in two slots used in turn: 2/parts of that (8 parts: 3.2 GB at N = 2^20, 19 GB at
- * 2^22), for one launch tail (~0.2 ms) per extra part.  0: the default (NBODY_DEFAULT_SUMMATION_PARTS).  Systems too small
+ * 2^22), for one launch tail (~0.2 ms) per extra part (measured at N = 2^20: 8 parts cost ~1 % of the step against 1).  0: the default (NBODY_DEFAULT_SUMMATION_PARTS).  Systems too small
  * for several launches, shards and column-range calls always take one part.  nbody_set_early_summation(on) is
  * nbody_set_summation_parts(on ? 0 : 1). */
 int nbody_set_summation_parts(nbody_ctx *ctx, int parts);
