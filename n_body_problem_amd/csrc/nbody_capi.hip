@@ -911,6 +911,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         // one-column loops (170 ms) -- A/B measurement
         static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 2;
         sa.packed = c->rows_per_lane == 8 ? 2 : c->rows_per_lane == 4 ? 1 : packed_env;  // nbody_set_rows_per_lane: A/B in one process
+        if (sa.packed == 2 && !c->equal_mass_path)
+            sa.packed = 1;  // no tile can take the eight-row loop: the four-row kernel (5 waves per SIMD) runs the general loop 1 % faster
         auto part_args = [&](const nbody_ctx::SymPart &p) {
             sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;
             sa.col_partials = c->col_partials + p.col_off;
