@@ -891,15 +891,13 @@ static hipError_t sym_launch_diag(const SymArgs &a, size_t lds, hipStream_t stre
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
 {
     // eight rows per lane for the equal-mass tiles (packed == 2): half the waves per split, 512 rows each
-    // (512-body splits, one wave per workgroup, measured 0.8 % slower than the four-row loop: N = 131072)
-    if (a.packed == 2 && !a.eps_pp && a.eps2 > 0.f && a.split_len % 512 == 0 && a.split_len >= 1024) {
-        const int w8 = a.split_len >= 2048 ? 4 : a.split_len / 512;
+    // (512-body splits, one wave per workgroup, measured 0.8 % slower than the four-row loop at N = 131072: multiples of
+    // 1024 only)
+    if (a.packed == 2 && !a.eps_pp && a.eps2 > 0.f && a.split_len % 1024 == 0) {
+        const int w8 = a.split_len % 2048 == 0 ? 4 : 2;  // whole passes of 512 rows per wave
         const size_t lds8 = sym_lds_bytes_for(w8, a.split_len);
-        switch (w8) {
-        case 4: return sym_launch(&force_sym_kernel<4, false, true>, a.n_tiles, 4, lds8, a, stream);
-        case 2: return sym_launch(&force_sym_kernel<2, false, true>, a.n_tiles, 2, lds8, a, stream);
-        default: return sym_launch(&force_sym_kernel<1, false, true>, a.n_tiles, 1, lds8, a, stream);
-        }
+        return w8 == 4 ? sym_launch(&force_sym_kernel<4, false, true>, a.n_tiles, 4, lds8, a, stream)
+                       : sym_launch(&force_sym_kernel<2, false, true>, a.n_tiles, 2, lds8, a, stream);
     }
     const size_t lds = symmetric_lds_bytes(a.split_len);
     switch (sym_waves(a.split_len)) {

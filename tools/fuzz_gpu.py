@@ -60,7 +60,7 @@ def main():
     worst = {"pair_vs_one": 0.0, "one_vs_f64": 0.0, "pair_vs_f64": 0.0}
     for case in range(cases):
         n = int(rng.choice([rng.integers(1, 600), rng.integers(600, 6000), rng.integers(6000, 40000)]))
-        L = int(rng.choice([256, 512, 768, 1024, 1280, 2048, 4096]))
+        L = int(rng.choice([256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096]))
         eps = float(rng.choice([0.0, 1e-3, 1e-2]))
         pos = np.empty((n, 4), np.float32)
         pos[:, :3] = rng.normal(size=(n, 3)).astype(np.float32) * rng.choice([0.1, 1.0, 30.0])
