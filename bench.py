@@ -154,11 +154,13 @@ def roofline(mode, n, split_len, rows_here, steps, tm, equal_mass=True):
                     "kernel.  Rank 0's kernels."}
 
 
-def other_mode_leg(nb, mode, n, pos, vel, args, equal_mass_path=True):
-    """Another kernel on the same state and GPU (N = 1 run only): the force mode that is NOT the headline, or the
-    headline mode with the equal-mass inner loop switched off (every split down the general-mass path)."""
+def other_mode_leg(nb, mode, n, pos, vel, args, equal_mass_path=True, body_order=None):
+    """Another kernel on the same state and GPU (N = 1 run only): the force mode that is NOT the headline, the headline
+    mode with the equal-mass inner loop switched off (every split down the general-mass path), or the headline mode with
+    the bodies left in the order the generator produced them."""
     import torch
-    s = nb.NBodySystem(n, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0)
+    s = nb.NBodySystem(n, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0,
+                       body_order=body_order or args.body_order)
     s.set_force_mode(mode)
     s.set_equal_mass_path(equal_mass_path)
     s.setParticlesPosition(pos)
@@ -175,8 +177,8 @@ def other_mode_leg(nb, mode, n, pos, vel, args, equal_mass_path=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = s.read_timing()
-    out = {"force_mode": mode, "value": float(n) * n * steps / dt, "unit": "interactions/s", "ms_per_step": 1e3 * dt / steps,
-           "steps": steps, "roofline": roofline(mode, n, s.split_len, n, steps, tm, equal_mass_path)}
+    out = {"force_mode": mode, "body_order": s.body_order, "value": float(n) * n * steps / dt, "unit": "interactions/s",
+           "ms_per_step": 1e3 * dt / steps, "steps": steps, "roofline": roofline(mode, n, s.split_len, n, steps, tm, equal_mass_path)}
     s.close()
     return out
 
@@ -242,6 +244,10 @@ def main():
     ap.add_argument("--softening", type=float, default=1e-3)
     ap.add_argument("--exchange", default=os.environ.get("NBODY_EXCHANGE", "allgather"), choices=["allgather", "ring"])
     ap.add_argument("--rows-per-lane", type=int, default=0)
+    ap.add_argument("--body-order", default=os.environ.get("NBODY_BODY_ORDER", "morton"), choices=["morton", "given"],
+                    help="how the library stores the bodies it is given: along a Morton curve (nbody_morton_order at upload, "
+                         "undone at download: neighbours in memory are neighbours in space, fewer operand bits toggle, the "
+                         "power-limited clock rises) or in the generator's (random) order; the other one is reported as a leg")
     ap.add_argument("--force-mode", default=os.environ.get("NBODY_FORCE_MODE", "pair_once"),
                     choices=["pair_once", "one_sided", "symmetric"],
                     help="pair_once (= symmetric): each unordered pair once; one_sided: every ordered interaction")
@@ -290,12 +296,14 @@ def main():
     n = args.n
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
     if world == 1:
-        system = nb.NBodySystem(n, device=local_rank, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0)
+        system = nb.NBodySystem(n, device=local_rank, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0,
+                                body_order=args.body_order)
         system.set_force_mode(mode)
         kernels = system
     else:
         # nccl backend: MultiGpuSystem, the exchange inside the library; gloo: the host-staged rehearsal harness
-        system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode)
+        system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode,
+                                body_order=args.body_order if args.backend == "nccl" else "given")
         kernels = system.kernels
     library_exchange = isinstance(system, MultiGpuSystem)
     rccl_ranks = system.info()["rccl_ranks"] if library_exchange else None
@@ -376,7 +384,10 @@ def main():
                                           "torch.distributed rehearsal harness") if world > 1 else None,
                        "rccl_ranks": rccl_ranks,
                        "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3],
-                       "force_mode": mode},
+                       "force_mode": mode,
+                       # the layout the library keeps the generator's bodies in (upload option, undone at download; the
+                       # other order is the `other_body_order` leg of the N = 1 run)
+                       "body_order": getattr(system, "body_order", "given")},
             "roofline": roofline(mode, n, int(getattr(system, "split_len", 0)), rows_here, args.steps, tm,
                                  equal_mass=bool(np.all(pos[:, 3] == pos[0, 3]))),
             "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
@@ -392,6 +403,8 @@ def main():
         if world == 1 and not args.no_extra_legs:
             out["other_force_mode"] = other_mode_leg(nb, "one_sided" if mode == "pair_once" else "pair_once", n, pos, vel, args)
             out["general_mass_path"] = other_mode_leg(nb, mode, n, pos, vel, args, equal_mass_path=False)
+            out["other_body_order"] = other_mode_leg(nb, mode, n, pos, vel, args,
+                                                     body_order="given" if args.body_order == "morton" else "morton")
             out["reference_size"] = reference_size_leg(nb)
             both = {mode: out["roofline"], out["other_force_mode"]["force_mode"]: out["other_force_mode"]["roofline"]}
             out["north_star_target"] = {

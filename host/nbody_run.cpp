@@ -22,7 +22,7 @@
 static void usage()
 {
     std::cerr << "usage: nbody_run [dataset_id 0-5] [--data-dir DIR] [--file PATH] [--plummer N] [--seed S] [--resume SNAPSHOT]\n"
-                 "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P]\n"
+                 "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P] [--morton]\n"
                  "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once] [--particle-softening]\n"
                  "                 [--devices D0,D1,...] [--ring] [--peer-copy]      rows sharded over several GPUs (library-owned exchange)\n";
 }
@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     std::int64_t plummer_n = 0, steps = 100, energy_every = 0, dump_every = 0;
     std::uint64_t seed = 0x5EED0003ull;
     float dt = nbody::kTimeTick, softening = nbody::kSofteningVersion3;  // the reference's constants
-    bool pad = false, kdk = false, pair_once = false, particle_eps = false, ring = false, peer_copy = false;
+    bool pad = false, kdk = false, pair_once = false, particle_eps = false, ring = false, peer_copy = false, morton = false;
     std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -62,6 +62,7 @@ int main(int argc, char **argv)
         }
         else if (a == "--ring") ring = true;
         else if (a == "--peer-copy") peer_copy = true;
+        else if (a == "--morton") morton = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-') {
             dataset = std::atoi(a.c_str());  // kernel.cu:1069-1086: argv[1] = dataset id, 0..5
@@ -79,6 +80,30 @@ int main(int argc, char **argv)
         const std::int64_t n_real = b.n();
         if (pad) nbody_io::pad_reference_style(b);  // accepted, never required (kernel.cu:260-278)
         std::printf("num of Bodies = %lld (real %lld)  dt = %g  softening = %g\n", (long long)b.n(), (long long)n_real, dt, softening);
+        // --morton: the bodies are stored along a Morton curve (nbody_morton_order: neighbours in memory are neighbours in
+        // space, the force kernels' operands toggle fewer bits, the power-limited clock rises); snapshots keep the file's order
+        std::vector<std::int64_t> order;
+        if (morton && b.n() > 0) {
+            order.resize((size_t)b.n());
+            if (nbody_morton_order(b.pos.data(), b.n(), order.data()) != NBODY_OK) throw std::runtime_error("nbody_morton_order failed");
+            nbody_io::Bodies sorted = b;
+            for (std::int64_t k = 0; k < b.n(); ++k)
+                for (int c = 0; c < 4; ++c) {
+                    sorted.pos[4 * (size_t)k + c] = b.pos[4 * (size_t)order[(size_t)k] + c];
+                    sorted.vel[4 * (size_t)k + c] = b.vel[4 * (size_t)order[(size_t)k] + c];
+                }
+            b = sorted;
+        }
+        auto save = [&](const std::string &name, std::int64_t step, double time) {  // b holds the device's order
+            if (order.empty()) { nbody_io::save_snapshot(name, b, step, time); return; }
+            nbody_io::Bodies out = b;
+            for (std::int64_t k = 0; k < b.n(); ++k)
+                for (int c = 0; c < 4; ++c) {
+                    out.pos[4 * (size_t)order[(size_t)k] + c] = b.pos[4 * (size_t)k + c];
+                    out.vel[4 * (size_t)order[(size_t)k] + c] = b.vel[4 * (size_t)k + c];
+                }
+            nbody_io::save_snapshot(name, out, step, time);
+        };
 
         if (!devices.empty()) {  // rows sharded over the listed GPUs; everything per step happens inside the library
             nbody::MultiSystem ms;
@@ -117,7 +142,7 @@ int main(int argc, char **argv)
                     ms.download(b.pos.data(), b.vel.data());
                     char name[512];
                     std::snprintf(name, sizeof name, "%s_%06lld.nbs", dump_prefix.c_str(), (long long)gs);
-                    nbody_io::save_snapshot(name, b, gs, time0 + (double)s * dt);
+                    save(name, gs, time0 + (double)s * dt);
                 }
             }
             const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -128,7 +153,7 @@ int main(int argc, char **argv)
                         tm.forceMs / (double)steps, tm.updateMs / (double)steps, ms.replicasIdentical() ? "yes" : "NO");
             if (!final_path.empty()) {
                 ms.download(b.pos.data(), b.vel.data());
-                nbody_io::save_snapshot(final_path, b, step0 + steps, time0 + (double)steps * dt);
+                save(final_path, step0 + steps, time0 + (double)steps * dt);
             }
             return 0;
         }
@@ -164,7 +189,7 @@ int main(int argc, char **argv)
                 sys.download(b.pos.data(), b.vel.data());
                 char name[512];
                 std::snprintf(name, sizeof name, "%s_%06lld.nbs", dump_prefix.c_str(), (long long)gs);
-                nbody_io::save_snapshot(name, b, gs, time0 + (double)s * dt);
+                save(name, gs, time0 + (double)s * dt);
             }
         }
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -174,7 +199,7 @@ int main(int argc, char **argv)
                     (long long)steps, wall, 1e3 * wall / (double)steps, inter / wall, tm.forceMs / (double)steps, tm.updateMs / (double)steps);
         if (!final_path.empty()) {
             sys.download(b.pos.data(), b.vel.data());
-            nbody_io::save_snapshot(final_path, b, step0 + steps, time0 + (double)steps * dt);
+            save(final_path, step0 + steps, time0 + (double)steps * dt);
         }
     } catch (const std::exception &ex) {
         std::cerr << "nbody_run: " << ex.what() << "\n";

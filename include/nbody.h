@@ -70,6 +70,21 @@ int64_t nbody_default_split_len(int64_t n_total);
 int64_t nbody_split_len(const nbody_ctx *ctx);
 int64_t nbody_n_total(const nbody_ctx *ctx);
 
+/* ---- body order (host helper, no device work) ----
+ * The force kernels run at the clock the power limit leaves them, and the power follows the operands: when neighbours
+ * in the arrays are neighbours in space, consecutive pair evaluations toggle fewer bits -- the same N = 2^20 Plummer
+ * sphere stored along a Morton curve instead of in random order runs its force pass 3.7 % faster, same instructions
+ * (profiles/r02_body_order_force_pass.txt).  The reference draws whatever order its loader produced (kernel.cu:190-556);
+ * order is not part of the physics.  nbody_morton_order fills perm[k] = the index, in the caller's arrays, of the body to
+ * store at slot k: along a Morton curve (21 bits per axis over the bounding cube of the finite positions; ties by index),
+ * and, when the set has at most NBODY_ORDER_MAX_SPECIES distinct masses, the bodies of one mass together in order of mass
+ * (so that the splits of a few-species set each keep one mass -- the equal-mass inner loops -- wherever the species were
+ * stored).  Deterministic; a pure function of the n float4 {x, y, z, m}.  The host layers apply it at upload and undo it
+ * at download (n_body_problem_amd.NBodySystem(body_order="morton"), nbody_run --morton); with caller-owned device
+ * buffers the caller stores its bodies that way itself. */
+#define NBODY_ORDER_MAX_SPECIES 16
+int nbody_morton_order(const float *host_xyzm, int64_t n, int64_t *perm);
+
 /* ---- context-owned buffers: setParticlesPosition / setParticlesVelocity, kernel.cu:163-188 ----
  * Host arrays of n_total float4 (positions) and row_count float4 (velocities of this context's rows).
  * Allocates the device buffers on first use.  nbody_download copies back; either pointer may be NULL. */

@@ -76,6 +76,7 @@ _PROTOTYPES = {
     "nbody_set_equal_mass_path": (c_int, [c_void_p, c_int]),
     "nbody_set_early_summation": (c_int, [c_void_p, c_int]),
     "nbody_set_summation_parts": (c_int, [c_void_p, c_int]),
+    "nbody_morton_order": (c_int, [c_void_p, c_int64, c_void_p]),
     "nbody_partial_sum_bytes": (c_int64, [c_void_p]),
     "nbody_device_info": (c_int, [c_void_p, POINTER(c_int64), c_char_p, c_int]),
     # multi-GPU (csrc/nbody_multi.hip)

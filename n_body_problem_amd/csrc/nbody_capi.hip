@@ -4,7 +4,9 @@
 #include "../../include/nbody.h"
 #include "nbody_kernels.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -166,6 +168,78 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
     while (len < 4096 && pairs16 / (double)len > 150e9)
         len *= 2;
     return len;
+}
+
+int nbody_morton_order(const float *xyzm, int64_t n, int64_t *perm)
+{
+    if (n < 0 || (n > 0 && (!xyzm || !perm)))
+        return NBODY_ERR_INVALID;
+    // the bounding cube of the finite positions
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+    bool any = false;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *p = xyzm + 4 * i;
+        if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])))
+            continue;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = any ? std::min(lo[a], p[a]) : p[a];
+            hi[a] = any ? std::max(hi[a], p[a]) : p[a];
+        }
+        any = true;
+    }
+    double extent = 0.0;
+    for (int a = 0; a < 3; ++a)
+        extent = std::max(extent, (double)hi[a] - (double)lo[a]);
+    const double scale = extent > 0.0 ? 2097151.0 / extent : 0.0;  // 21 bits per axis
+    auto spread = [](uint64_t v) {  // bit k of v to bit 3k
+        v &= 0x1fffffull;
+        v = (v | v << 32) & 0x1f00000000ffffull;
+        v = (v | v << 16) & 0x1f0000ff0000ffull;
+        v = (v | v << 8) & 0x100f00f00f00f00full;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+        v = (v | v << 2) & 0x1249249249249249ull;
+        return v;
+    };
+    // few species: the mass first (rank of the mass among the distinct values), then the curve
+    std::vector<uint32_t> species;
+    bool few = true;
+    for (int64_t i = 0; i < n && few; ++i) {
+        uint32_t bits;
+        std::memcpy(&bits, xyzm + 4 * i + 3, 4);
+        if (std::find(species.begin(), species.end(), bits) == species.end()) {
+            species.push_back(bits);
+            few = species.size() <= NBODY_ORDER_MAX_SPECIES;
+        }
+    }
+    if (few)
+        std::sort(species.begin(), species.end(), [](uint32_t a, uint32_t b) {
+            float fa, fb;
+            std::memcpy(&fa, &a, 4);
+            std::memcpy(&fb, &b, 4);
+            return fa < fb || (!(fb < fa) && a < b);  // by value; NaNs and signed zeros by bit pattern
+        });
+    struct Key { uint64_t curve; uint32_t species; int64_t index; };
+    std::vector<Key> keys((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const float *p = xyzm + 4 * i;
+        uint64_t q[3] = {0, 0, 0};
+        const bool finite = std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
+        for (int a = 0; a < 3 && finite; ++a)
+            q[a] = (uint64_t)std::min(2097151.0, std::max(0.0, ((double)p[a] - (double)lo[a]) * scale));
+        uint32_t bits, rank = 0;
+        std::memcpy(&bits, p + 3, 4);
+        if (few)
+            rank = (uint32_t)(std::find(species.begin(), species.end(), bits) - species.begin());
+        keys[(size_t)i] = Key{finite ? (spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2) : ~0ull, rank, i};
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.species != b.species) return a.species < b.species;
+        if (a.curve != b.curve) return a.curve < b.curve;
+        return a.index < b.index;
+    });
+    for (int64_t k = 0; k < n; ++k)
+        perm[k] = keys[(size_t)k].index;
+    return NBODY_OK;
 }
 
 int64_t nbody_split_len(const nbody_ctx *ctx) { return ctx ? ctx->split_len : 0; }

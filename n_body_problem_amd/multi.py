@@ -74,7 +74,12 @@ class MultiGpuSystem:
 
     def __init__(self, num_bodies: int, devices: Optional[Sequence[int]] = None, force_mode: str = "one_sided",
                  integrator: str = "kick_drift", exchange: str = "allgather", transport: str = "rccl", split_len: int = 0,
+                 body_order: str = "given",
                  _rank: Optional[int] = None, _world_size: Optional[int] = None, _unique_id: Optional[bytes] = None):
+        if body_order not in _system.BODY_ORDERS:
+            raise ValueError(f"body_order must be one of {_system.BODY_ORDERS}")
+        self.body_order = body_order   # "morton": the state is stored in system.morton_order, download() undoes it
+        self.order = None
         self._m = ctypes.c_void_p(None)
         self._lib = _lib.load()
         self.num_bodies = int(num_bodies)
@@ -177,8 +182,12 @@ class MultiGpuSystem:
 
     # -- buffers (kernel.cu:163-188) -----------------------------------------------------------------
     def _upload(self) -> None:
-        _check(self._lib.nbody_multi_set_state(self._m, self._pos.ctypes.data_as(ctypes.c_void_p),
-                                               self._vel.ctypes.data_as(ctypes.c_void_p)), self._m)
+        pos, vel = self._pos, self._vel
+        if self.body_order == "morton":  # a function of the positions: the same on every process
+            self.order = _system.morton_order(pos)
+            pos, vel = np.ascontiguousarray(pos[self.order]), np.ascontiguousarray(vel[self.order])
+        _check(self._lib.nbody_multi_set_state(self._m, pos.ctypes.data_as(ctypes.c_void_p),
+                                               vel.ctypes.data_as(ctypes.c_void_p)), self._m)
 
     def _rows(self, data) -> np.ndarray:
         a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
@@ -210,6 +219,10 @@ class MultiGpuSystem:
         e = np.ascontiguousarray(eps, dtype=np.float32).reshape(-1)
         if e.shape[0] != self.num_bodies:
             raise ValueError(f"expected {self.num_bodies} softening lengths, got {e.shape[0]}")
+        if self.body_order == "morton":
+            if self.order is None:
+                raise NBodyError(_lib.NBODY_ERR_STATE, "body_order='morton': set the positions before the softening lengths")
+            e = np.ascontiguousarray(e[self.order])
         _check(self._lib.nbody_multi_set_particle_softening(self._m, e.ctypes.data_as(ctypes.c_void_p)), self._m)
 
     def download(self) -> Tuple[np.ndarray, np.ndarray]:
@@ -218,6 +231,10 @@ class MultiGpuSystem:
         v = np.empty((self.num_bodies, 4), dtype=np.float32)
         _check(self._lib.nbody_multi_download(self._m, p.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)),
                self._m)
+        if self.order is not None:  # back to the caller's order
+            pc, vc = np.empty_like(p), np.empty_like(v)
+            pc[self.order], vc[self.order] = p, v
+            return pc, vc
         return p, v
 
     # -- the step (kernel.cu:1225-1242) ---------------------------------------------------------------

@@ -322,7 +322,7 @@ class ShardedNBodySystem:
 
 
 def sharded_system(num_bodies: int, device: int = 0, group=None, exchange: str = "allgather", force_mode: str = "one_sided",
-                   integrator: str = "kick_drift", split_len: int = 0):
+                   integrator: str = "kick_drift", split_len: int = 0, body_order: str = "given"):
     """The sharded system of this process's rank: the library-owned RCCL exchange (``MultiGpuSystem``) when the process
     group's backend is ``nccl`` or there is no process group, the host-staged rehearsal harness otherwise (gloo)."""
     import torch.distributed as dist
@@ -330,6 +330,8 @@ def sharded_system(num_bodies: int, device: int = 0, group=None, exchange: str =
     if not distributed or dist.get_backend(group) == "nccl":
         from .multi import MultiGpuSystem
         return MultiGpuSystem.from_torch_distributed(num_bodies, device, group=group, exchange=exchange, force_mode=force_mode,
-                                                     integrator=integrator, split_len=split_len)
+                                                     integrator=integrator, split_len=split_len, body_order=body_order)
+    if body_order != "given":
+        raise ValueError("the rehearsal harness keeps the caller's body order")
     return ShardedNBodySystem(num_bodies, group=group, device=device, exchange=exchange, force_mode=force_mode,
                               integrator=integrator, split_len=split_len)

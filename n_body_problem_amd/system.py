@@ -49,14 +49,37 @@ def default_split_len(n_total: int) -> int:
     return int(_lib.load().nbody_default_split_len(int(n_total)))
 
 
+BODY_ORDERS = ("given", "morton")
+
+
+def morton_order(positions) -> np.ndarray:
+    """``perm[k]`` = index of the body to store at slot ``k`` (``nbody_morton_order``: along a Morton curve, the bodies of one
+    mass together when there are few distinct masses).  Neighbours in the arrays become neighbours in space, the force
+    kernels' operands toggle fewer bits and the power-limited clock rises: 3.7 % per force pass at N = 2^20."""
+    a = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 4)
+    perm = np.empty(a.shape[0], dtype=np.int64)
+    status = _lib.load().nbody_morton_order(a.ctypes.data_as(ctypes.c_void_p), a.shape[0], perm.ctypes.data_as(ctypes.c_void_p))
+    if status != 0:
+        raise NBodyError(status, "nbody_morton_order failed")
+    return perm
+
+
 class NBodySystem:
     """One context = one GPU's rows ``[row_lo, row_lo+row_count)`` against all ``num_bodies`` columns.
 
     With the defaults it is the reference's single-GPU system: ``initialize(numBodies)``.
+
+    ``body_order="morton"`` (a context that owns every row): ``setParticlesPosition`` stores the bodies in
+    :func:`morton_order`, ``setParticlesVelocity`` follows, :meth:`download` undoes it; ``self.order[k]`` is the caller's index
+    of the body in slot ``k`` of the device tensors.  The physics is the same, the sums are taken in another order.
     """
 
     def __init__(self, num_bodies: int, device: int = 0, row_lo: int = 0, row_count: Optional[int] = None,
-                 split_len: int = 0):
+                 split_len: int = 0, body_order: str = "given"):
+        if body_order not in BODY_ORDERS:
+            raise ValueError(f"body_order must be one of {BODY_ORDERS}")
+        self.body_order = body_order
+        self.order = None       # the permutation in use (set by setParticlesPosition)
         self._ctx = ctypes.c_void_p(None)
         self._lib = _lib.load()
         torch = _torch()
@@ -71,6 +94,9 @@ class NBodySystem:
                                            int(split_len)), None)
         self._ctx = ctx
         self.split_len = int(self._lib.nbody_split_len(ctx))
+        if body_order != "given" and (self.row_lo != 0 or self.row_count != self.num_bodies):
+            self.close()
+            raise ValueError("body_order needs a context that owns every row (shards: MultiGpuSystem(body_order=...))")
         self._eps_pp = None
         # the reference's two device buffers: position "VBO" (all bodies) and velocities (own rows)
         self.positions = torch.zeros((self.num_bodies, 4), dtype=torch.float32, device=self.device)
@@ -106,6 +132,9 @@ class NBodySystem:
         a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
         if a.shape[0] != self.num_bodies:
             raise ValueError(f"expected {self.num_bodies} bodies, got {a.shape[0]}")
+        if self.body_order == "morton":
+            self.order = morton_order(a)
+            a = np.ascontiguousarray(a[self.order])
         self.positions.copy_(torch.from_numpy(a))
         self._lib.nbody_invalidate_forces(self._ctx)
 
@@ -119,14 +148,23 @@ class NBodySystem:
             a = a[self.row_lo:self.row_lo + self.row_count]
         if a.shape[0] != self.row_count:
             raise ValueError(f"expected {self.row_count} or {self.num_bodies} velocity rows, got {a.shape[0]}")
+        if self.body_order == "morton":
+            if self.order is None:
+                raise NBodyError(_lib.NBODY_ERR_STATE, "body_order='morton': call setParticlesPosition before setParticlesVelocity")
+            a = a[self.order]
         self.velocities.copy_(torch.from_numpy(np.ascontiguousarray(a)))
 
     set_particles_position = setParticlesPosition
     set_particles_velocity = setParticlesVelocity
 
     def download(self) -> Tuple[np.ndarray, np.ndarray]:
-        """(positions, velocities) as host float32 arrays."""
-        return self.positions.cpu().numpy(), self.velocities.cpu().numpy()
+        """(positions, velocities) as host float32 arrays, in the caller's body order."""
+        pos, vel = self.positions.cpu().numpy(), self.velocities.cpu().numpy()
+        if self.order is not None:
+            p, v = np.empty_like(pos), np.empty_like(vel)
+            p[self.order], v[self.order] = pos, vel
+            return p, v
+        return pos, vel
 
     # -- the step (kernel.cu:1225-1242) ---------------------------------------------------------
     def step(self, dt: float = TIME_TICK, softening: float = SOFTENING_VERSION3, masses=None, sync: bool = True):
@@ -136,6 +174,8 @@ class NBodySystem:
         ``positions[:,3]``; the default, as in the reference, is that mass already lives there."""
         self._use_current_stream()
         fn = self._lib.nbody_step if sync else self._lib.nbody_step_async
+        if masses is not None and self.order is not None:
+            masses = masses.reshape(-1)[_torch().from_numpy(self.order).to(self.device)].contiguous()
         check(fn(self._ctx, _ptr(self.positions), _ptr(self.velocities), _ptr(masses), float(dt), float(softening)),
               self._ctx)
 
@@ -261,6 +301,8 @@ class NBodySystem:
             t = t.to(device=self.device, dtype=torch.float32).contiguous()
             if t.numel() != self.num_bodies:
                 raise ValueError(f"expected {self.num_bodies} softening lengths, got {t.numel()}")
+            if self.order is not None:  # the caller's order -> the order of the device buffers
+                t = t.reshape(-1)[torch.from_numpy(self.order).to(self.device)].contiguous()
             self._eps_pp = t  # keeps the borrowed device buffer alive
         check(self._lib.nbody_set_particle_softening(self._ctx, _ptr(self._eps_pp)), self._ctx)
 

@@ -38,11 +38,25 @@ def main():
     ap.add_argument("--split-len", type=int, default=0)
     ap.add_argument("--symmetric", action="store_true", help="time the experimental pair-once kernel (rpl is ignored)")
     ap.add_argument("--general-masses", action="store_true", help="equal-mass inner loops off: every split down the general path")
+    ap.add_argument("--order", default="given", choices=["given", "morton", "radius"],
+                    help="body order: as generated (random), along a Morton curve, or by distance from the centre (operand "
+                         "toggling experiment: neighbours in index are neighbours in space)")
     args = ap.parse_args()
 
     import torch
     import n_body_problem_amd as nb
     pos, vel = nb.plummer(args.n, seed=nb.CONFIG_SEED[3])
+    if args.order == "morton":
+        q = np.clip(((pos[:, :3] + 4.0) / 8.0 * 1024).astype(np.int64), 0, 1023)
+        key = np.zeros(args.n, np.int64)
+        for b in range(10):
+            for a in range(3):
+                key |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        perm = np.argsort(key, kind="stable")
+        pos, vel = np.ascontiguousarray(pos[perm]), np.ascontiguousarray(vel[perm])
+    elif args.order == "radius":
+        perm = np.argsort(np.linalg.norm(pos[:, :3], axis=1), kind="stable")
+        pos, vel = np.ascontiguousarray(pos[perm]), np.ascontiguousarray(vel[perm])
     dpos = torch.from_numpy(pos).cuda()
     dvel = torch.from_numpy(vel).cuda()
     torch.cuda.synchronize()
