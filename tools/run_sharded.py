@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "ring"])
     ap.add_argument("--split-len", type=int, default=0, help="0 = the mode's default for this body count")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--body-order", default="given", choices=["given", "morton"],
+                    help="morton: the library stores the bodies along a Morton curve (3-4 %% more clock); nccl backend only")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
@@ -49,7 +51,7 @@ def main():
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[5])
     # nccl backend (or a single process): the exchange runs inside the library (nbody_multi_*); gloo: the rehearsal harness
     s = sharded_system(n, device=local, exchange=args.exchange, force_mode=args.force_mode, integrator=args.integrator,
-                       split_len=args.split_len)
+                       split_len=args.split_len, body_order=args.body_order)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel)
     del pos, vel
