@@ -339,12 +339,13 @@ class NBodySystem:
 PAIR_ONCE_MIN_BODIES = 65536  # below it the pair-once grid is too coarse to fill the chip
 
 
-def initialize(num_bodies: int, device: int = 0, force_mode: str = "one_sided") -> NBodySystem:
+def initialize(num_bodies: int, device: int = 0, force_mode: str = "one_sided", body_order: str = "given") -> NBodySystem:
     """``initialize(numBodies)`` of kernel.cu:130-161.  ``force_mode``: ``"one_sided"``, ``"pair_once"`` or ``"auto"``
-    (pair-once from ``PAIR_ONCE_MIN_BODIES`` bodies on, where it is the faster one)."""
+    (pair-once from ``PAIR_ONCE_MIN_BODIES`` bodies on, where it is the faster one); ``body_order``: see :class:`NBodySystem`."""
     if force_mode == "auto":
         force_mode = "pair_once" if num_bodies >= PAIR_ONCE_MIN_BODIES else "one_sided"
-    s = NBodySystem(num_bodies, device=device, split_len=pair_once_split_len(num_bodies) if force_mode == "pair_once" else 0)
+    s = NBodySystem(num_bodies, device=device, split_len=pair_once_split_len(num_bodies) if force_mode == "pair_once" else 0,
+                    body_order=body_order)
     s.set_force_mode(force_mode)
     return s
 
