@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--split-len", type=int, default=0)
     ap.add_argument("--symmetric", action="store_true", help="time the experimental pair-once kernel (rpl is ignored)")
     ap.add_argument("--general-masses", action="store_true", help="equal-mass inner loops off: every split down the general path")
-    ap.add_argument("--order", default="given", choices=["given", "morton", "radius"],
+    ap.add_argument("--order", default="given", choices=["given", "morton", "radius", "hilbert"],
                     help="body order: as generated (random), along a Morton curve, or by distance from the centre (operand "
                          "toggling experiment: neighbours in index are neighbours in space)")
     args = ap.parse_args()
@@ -54,6 +54,37 @@ def main():
                 key |= ((q[:, a] >> b) & 1) << (3 * b + a)
         perm = np.argsort(key, kind="stable")
         pos, vel = np.ascontiguousarray(pos[perm]), np.ascontiguousarray(vel[perm])
+        print("mean neighbour distance:", float(np.linalg.norm(np.diff(pos[:, :3], axis=0), axis=1).mean()))
+    elif args.order == "hilbert":  # Skilling's transpose algorithm, 16 bits per axis
+        bits = 16
+        X = [np.clip(((pos[:, a] + 4.0) / 8.0 * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1) for a in range(3)]
+        M = 1 << (bits - 1)
+        Q = M
+        while Q > 1:
+            P = Q - 1
+            for i in range(3):
+                hit = (X[i] & Q) != 0
+                X[0] = np.where(hit, X[0] ^ P, X[0])
+                t = np.where(hit, 0, (X[0] ^ X[i]) & P)
+                X[0] ^= t
+                X[i] ^= t
+            Q >>= 1
+        for i in range(1, 3):
+            X[i] ^= X[i - 1]
+        t = np.zeros_like(X[0])
+        Q = M
+        while Q > 1:
+            t = np.where((X[2] & Q) != 0, t ^ (Q - 1), t)
+            Q >>= 1
+        for i in range(3):
+            X[i] ^= t
+        key = np.zeros(args.n, np.int64)
+        for b in range(bits - 1, -1, -1):
+            for i in range(3):
+                key = (key << 1) | ((X[i] >> b) & 1)
+        perm = np.argsort(key, kind="stable")
+        pos, vel = np.ascontiguousarray(pos[perm]), np.ascontiguousarray(vel[perm])
+        print("mean neighbour distance:", float(np.linalg.norm(np.diff(pos[:, :3], axis=0), axis=1).mean()))
     elif args.order == "radius":
         perm = np.argsort(np.linalg.norm(pos[:, :3], axis=1), kind="stable")
         pos, vel = np.ascontiguousarray(pos[perm]), np.ascontiguousarray(vel[perm])
