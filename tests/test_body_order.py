@@ -110,3 +110,30 @@ def test_morton_stored_shards_equal_one_morton_stored_context():
         s.step_n(3, 1e-3, 1e-3)
         want = s.download()
     assert np.array_equal(got[0][perm], want[0][:n]) and np.array_equal(got[1][perm], want[1][:n])
+
+
+@pytest.mark.gpu
+def test_headline_size_morton_stored_is_what_bench_runs(oracle_mod):
+    """bench.py's default configuration: N = 2^20, pair-once mode, bodies stored along the Morton curve.  One force pass
+    (zero velocities, dt = 1 leave the accelerations in the velocity buffer): sampled rows against the fp64 oracle, in the
+    caller's order; Newton's third law over all pairs; and the whole field against the generator's order."""
+    oracle = oracle_mod
+    n = 1 << 20
+    pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
+    acc = {}
+    for order in ("morton", "given"):
+        with nb.NBodySystem(n, split_len=nb.pair_once_split_len(n), body_order=order) as s:
+            s.set_force_mode("pair_once")
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(np.zeros_like(vel))
+            s.step(1.0, 1e-3)
+            p, v = s.download()
+            assert np.array_equal(p[:, 3], pos[:, 3]) and np.all(v[:, 3] == 0)
+            acc[order] = v[:, :3].astype(np.float64)
+    for lo, hi in ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n)):
+        a64 = oracle.accel_f64(pos, i0=lo, i1=hi, eps=1e-3)
+        assert np.linalg.norm(acc["morton"][lo:hi] - a64) / np.linalg.norm(a64) < 1e-5
+    mass = pos[:, 3].astype(np.float64)
+    net = (mass[:, None] * acc["morton"]).sum(0)
+    assert np.all(np.abs(net) < 1e-5 * (mass[:, None] * np.abs(acc["morton"])).sum(0))
+    assert np.linalg.norm(acc["morton"] - acc["given"]) <= 1e-6 * np.linalg.norm(acc["given"])
