@@ -260,8 +260,15 @@ def _one_rank_under_torch_nccl(rank, port, out_path):
         t = torch.ones(1, device="cuda")
         dist.all_reduce(t)                                                           # torch's communicator beside the library's
         p, v = s.download()
+        # and bench.py's default layout: the bodies stored along the Morton curve, through the same factory
+        m = sharded_system(n, device=0, force_mode="pair_once", body_order="morton")
+        m.setParticlesPosition(pos)
+        m.setParticlesVelocity(vel)
+        m.step_n(3, DT, EPS)
+        pm, vm = m.download()
         np.savez(out_path, p=p, v=v, e=s.energy(EPS), rccl_ranks=s.info()["rccl_ranks"], same=s.replicas_identical(),
-                 n_padded=s.n_padded, split_len=s.split_len, t=float(t.item()))
+                 n_padded=s.n_padded, split_len=s.split_len, t=float(t.item()), pm=pm, vm=vm, order=m.order)
+        m.close()
         s.close()
     finally:
         dist.destroy_process_group()
@@ -284,3 +291,7 @@ def test_library_exchange_beside_torch_distributed_nccl(tmp_path):
     pos, vel = nb.plummer(8192, seed=8)
     want_p, want_v, want_e, _ = one_context(nb, pos, vel, int(g["n_padded"]), int(g["split_len"]), 3, "pair_once")
     assert np.array_equal(g["p"], want_p) and np.array_equal(g["v"], want_v) and np.allclose(g["e"], want_e, rtol=1e-9)
+    perm = nb.morton_order(pos)
+    assert np.array_equal(g["order"], perm)
+    sorted_p, sorted_v, _, _ = one_context(nb, pos[perm], vel[perm], int(g["n_padded"]), int(g["split_len"]), 3, "pair_once")
+    assert np.array_equal(g["pm"][perm], sorted_p) and np.array_equal(g["vm"][perm], sorted_v)
