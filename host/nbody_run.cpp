@@ -83,7 +83,7 @@ int main(int argc, char **argv)
         // --morton: the bodies are stored along a Morton curve (nbody_morton_order: neighbours in memory are neighbours in
         // space, the force kernels' operands toggle fewer bits, the power-limited clock rises); snapshots keep the file's order
         std::vector<std::int64_t> order;
-        if (morton && b.n() > 0) {
+        if (morton && b.n() > 0 && devices.empty()) {  // (with --devices the library does it: nbody_multi_config.body_order)
             order.resize((size_t)b.n());
             if (nbody_morton_order(b.pos.data(), b.n(), order.data()) != NBODY_OK) throw std::runtime_error("nbody_morton_order failed");
             nbody_io::Bodies sorted = b;
@@ -107,7 +107,7 @@ int main(int argc, char **argv)
 
         if (!devices.empty()) {  // rows sharded over the listed GPUs; everything per step happens inside the library
             nbody::MultiSystem ms;
-            ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy);
+            ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy, 0, morton);
             ms.setState(b.pos.data(), b.vel.data());
             ms.timing(true);
             if (particle_eps) {

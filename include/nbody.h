@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 2
+#define NBODY_ABI_VERSION 3
 #define NBODY_MIN_SOFTENING 1.0e-9f
 
 typedef struct nbody_ctx nbody_ctx;
@@ -83,6 +83,7 @@ int64_t nbody_n_total(const nbody_ctx *ctx);
  * at download (n_body_problem_amd.NBodySystem(body_order="morton"), nbody_run --morton); with caller-owned device
  * buffers the caller stores its bodies that way itself. */
 #define NBODY_ORDER_MAX_SPECIES 16
+enum { NBODY_ORDER_GIVEN = 0, NBODY_ORDER_MORTON = 1 };
 int nbody_morton_order(const float *host_xyzm, int64_t n, int64_t *perm);
 
 /* ---- context-owned buffers: setParticlesPosition / setParticlesVelocity, kernel.cu:163-188 ----
@@ -286,6 +287,10 @@ typedef struct nbody_multi_config {
     int integrator;    /* NBODY_INTEGRATOR_KICK_DRIFT | NBODY_INTEGRATOR_KDK */
     int exchange;      /* NBODY_EXCHANGE_* */
     int transport;     /* NBODY_TRANSPORT_* */
+    int body_order;    /* NBODY_ORDER_GIVEN | NBODY_ORDER_MORTON: nbody_multi_set_state stores the bodies in nbody_morton_order
+                          of the positions it is given (the same on every rank), nbody_multi_download and
+                          nbody_multi_set_particle_softening speak the caller's order; nbody_multi_order reads the permutation */
+    int reserved;      /* 0 */
 } nbody_multi_config;
 
 /* Pure host functions (no device needed): the padded size and rows per rank, and hop `hop` (1..P-1) of the ring. */
@@ -307,6 +312,9 @@ int nbody_multi_set_timeout(nbody_multi *m, double seconds);
 int nbody_multi_set_state(nbody_multi *m, const float *host_xyzm, const float *host_xyzw);
 int nbody_multi_set_particle_softening(nbody_multi *m, const float *host_eps);
 int nbody_multi_download(nbody_multi *m, float *host_xyzm, float *host_xyzw);
+/* perm[k] = the caller's index of the body stored in slot k of the replicas (the identity with NBODY_ORDER_GIVEN); n_bodies
+ * entries, valid after nbody_multi_set_state.  A renderer that reads nbody_multi_positions_device sees this order. */
+int nbody_multi_order(nbody_multi *m, int64_t *perm);
 
 /* The step.  nbody_multi_step / _step_n return with every replica current and all device work complete;
  * nbody_multi_step_async only enqueues (the exchange of the updated rows stays in flight under the next step). */

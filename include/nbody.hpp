@@ -131,7 +131,7 @@ public:
 
     // initialize(numBodies) on the given devices; pairOnce / kickDriftKick / ring / peerCopy select the variants
     void initialize(std::int64_t numBodies, const std::vector<int> &devices, bool pairOnce = false, bool kickDriftKick = false,
-                    bool ring = false, bool peerCopy = false, std::int64_t splitLen = 0)
+                    bool ring = false, bool peerCopy = false, std::int64_t splitLen = 0, bool mortonOrder = false)
     {
         nbody_multi_destroy(m_);
         m_ = nullptr;
@@ -142,6 +142,7 @@ public:
         cfg.integrator = kickDriftKick ? NBODY_INTEGRATOR_KDK : NBODY_INTEGRATOR_KICK_DRIFT;
         cfg.exchange = ring ? NBODY_EXCHANGE_RING : NBODY_EXCHANGE_ALLGATHER;
         cfg.transport = peerCopy ? NBODY_TRANSPORT_PEER_COPY : NBODY_TRANSPORT_RCCL;
+        cfg.body_order = mortonOrder ? NBODY_ORDER_MORTON : NBODY_ORDER_GIVEN;  // stored along a Morton curve, downloads undo it
         check(nbody_multi_create(&m_, &cfg, devices.data(), (int)devices.size()), "nbody_multi_create");
         n_ = numBodies;
     }

@@ -77,6 +77,7 @@ _PROTOTYPES = {
     "nbody_set_early_summation": (c_int, [c_void_p, c_int]),
     "nbody_set_summation_parts": (c_int, [c_void_p, c_int]),
     "nbody_morton_order": (c_int, [c_void_p, c_int64, c_void_p]),
+    "nbody_multi_order": (c_int, [c_void_p, c_void_p]),
     "nbody_partial_sum_bytes": (c_int64, [c_void_p]),
     "nbody_device_info": (c_int, [c_void_p, POINTER(c_int64), c_char_p, c_int]),
     # multi-GPU (csrc/nbody_multi.hip)
@@ -108,7 +109,7 @@ _PROTOTYPES = {
 class MultiConfig(ctypes.Structure):
     """``nbody_multi_config`` of include/nbody.h."""
     _fields_ = [("n_bodies", c_int64), ("split_len", c_int64), ("force_mode", c_int), ("integrator", c_int),
-                ("exchange", c_int), ("transport", c_int)]
+                ("exchange", c_int), ("transport", c_int), ("body_order", c_int), ("reserved", c_int)]
 
 _lib = None
 

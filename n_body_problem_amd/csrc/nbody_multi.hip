@@ -68,6 +68,7 @@ struct nbody_multi {
     int64_t n_bodies = 0, n_padded = 0, chunk = 0, split_len = 0;
     std::vector<Rank> ranks;  // the local ranks
     Channel ch_pos, ch_col;
+    std::vector<int64_t> order;  // NBODY_ORDER_MORTON: slot k of the replicas holds the caller's body order[k] (set by set_state)
     bool exchange_in_flight = false;  // the position exchange of the last update has been issued and not yet consumed
     bool kdk_ready = false;
     bool have_state = false;
@@ -250,7 +251,8 @@ static int create_common(nbody_multi **out, const nbody_multi_config *cfg, int w
     *out = nullptr;
     if (!cfg)
         return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: config is NULL");
-    if ((cfg->integrator != NBODY_INTEGRATOR_KICK_DRIFT && cfg->integrator != NBODY_INTEGRATOR_KDK) ||
+    if ((cfg->body_order != NBODY_ORDER_GIVEN && cfg->body_order != NBODY_ORDER_MORTON) ||
+        (cfg->integrator != NBODY_INTEGRATOR_KICK_DRIFT && cfg->integrator != NBODY_INTEGRATOR_KDK) ||
         (cfg->exchange != NBODY_EXCHANGE_ALLGATHER && cfg->exchange != NBODY_EXCHANGE_RING) ||
         (cfg->transport != NBODY_TRANSPORT_RCCL && cfg->transport != NBODY_TRANSPORT_PEER_COPY))
         return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: unknown integrator, exchange or transport");
@@ -901,7 +903,16 @@ extern "C" int nbody_multi_set_state(nbody_multi *m, const float *host_pos, cons
         return rc;
     // padding = zero-mass bodies at the origin, the reference's own device (kernel.cu:265-277): they add exactly 0
     std::vector<float> pos(4 * (size_t)m->n_padded, 0.f), vel(4 * (size_t)m->n_padded, 0.f);
-    if (m->n_bodies) {
+    m->order.clear();
+    if (m->n_bodies && m->cfg.body_order == NBODY_ORDER_MORTON) {  // slot k <- the caller's body order[k]; padding stays behind
+        m->order.resize((size_t)m->n_bodies);
+        if (nbody_morton_order(host_pos, m->n_bodies, m->order.data()) != NBODY_OK)
+            return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_state: nbody_morton_order failed");
+        for (int64_t k = 0; k < m->n_bodies; ++k) {
+            std::memcpy(&pos[4 * (size_t)k], host_pos + 4 * (size_t)m->order[(size_t)k], sizeof(float) * 4);
+            std::memcpy(&vel[4 * (size_t)k], host_vel + 4 * (size_t)m->order[(size_t)k], sizeof(float) * 4);
+        }
+    } else if (m->n_bodies) {
         std::memcpy(pos.data(), host_pos, sizeof(float) * 4 * (size_t)m->n_bodies);
         std::memcpy(vel.data(), host_vel, sizeof(float) * 4 * (size_t)m->n_bodies);
     }
@@ -930,7 +941,15 @@ extern "C" int nbody_multi_set_particle_softening(nbody_multi *m, const float *h
     std::vector<float> eps;
     if (host_eps) {
         eps.assign((size_t)m->n_padded, 0.f);
-        std::memcpy(eps.data(), host_eps, sizeof(float) * (size_t)m->n_bodies);
+        if (m->cfg.body_order == NBODY_ORDER_MORTON) {
+            if (m->order.size() != (size_t)m->n_bodies)
+                return mfail(m, NBODY_ERR_STATE, "nbody_multi_set_particle_softening: with NBODY_ORDER_MORTON call "
+                                                 "nbody_multi_set_state first (the order is a function of the positions)");
+            for (int64_t k = 0; k < m->n_bodies; ++k)
+                eps[(size_t)k] = host_eps[(size_t)m->order[(size_t)k]];
+        } else {
+            std::memcpy(eps.data(), host_eps, sizeof(float) * (size_t)m->n_bodies);
+        }
     }
     for (Rank &r : m->ranks)
         MCTX(m, r, nbody_upload_particle_softening(r.ctx, host_eps ? eps.data() : nullptr));
@@ -938,10 +957,41 @@ extern "C" int nbody_multi_set_particle_softening(nbody_multi *m, const float *h
     return NBODY_OK;
 }
 
+static int download_device_order(nbody_multi *m, float *host_pos, float *host_vel);
+
 extern "C" int nbody_multi_download(nbody_multi *m, float *host_pos, float *host_vel)
 {
     if (!m)
         return NBODY_ERR_INVALID;
+    if (m->order.empty())
+        return download_device_order(m, host_pos, host_vel);
+    // the replicas hold the bodies in nbody_morton_order: back to the caller's
+    std::vector<float> pos(host_pos ? 4 * (size_t)m->n_bodies : 0), vel(host_vel ? 4 * (size_t)m->n_bodies : 0);
+    int rc = download_device_order(m, host_pos ? pos.data() : nullptr, host_vel ? vel.data() : nullptr);
+    if (rc != NBODY_OK)
+        return rc;
+    for (int64_t k = 0; k < m->n_bodies; ++k) {
+        if (host_pos)
+            std::memcpy(host_pos + 4 * (size_t)m->order[(size_t)k], &pos[4 * (size_t)k], sizeof(float) * 4);
+        if (host_vel)
+            std::memcpy(host_vel + 4 * (size_t)m->order[(size_t)k], &vel[4 * (size_t)k], sizeof(float) * 4);
+    }
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_order(nbody_multi *m, int64_t *perm)
+{
+    if (!m || (!perm && m->n_bodies))
+        return NBODY_ERR_INVALID;
+    if (!m->have_state && m->n_bodies)
+        return mfail(m, NBODY_ERR_STATE, "nbody_multi_order: no state was ever set");
+    for (int64_t k = 0; k < m->n_bodies; ++k)
+        perm[k] = m->order.empty() ? k : m->order[(size_t)k];
+    return NBODY_OK;
+}
+
+static int download_device_order(nbody_multi *m, float *host_pos, float *host_vel)
+{
     if (!m->have_state && m->n_padded)
         return mfail(m, NBODY_ERR_STATE, "nbody_multi_download: no state was ever set");
     int rc = settle(m);

@@ -78,15 +78,14 @@ class MultiGpuSystem:
                  _rank: Optional[int] = None, _world_size: Optional[int] = None, _unique_id: Optional[bytes] = None):
         if body_order not in _system.BODY_ORDERS:
             raise ValueError(f"body_order must be one of {_system.BODY_ORDERS}")
-        self.body_order = body_order   # "morton": the state is stored in system.morton_order, download() undoes it
-        self.order = None
+        self.body_order = body_order   # "morton": the library stores the state in nbody_morton_order, download() undoes it
         self._m = ctypes.c_void_p(None)
         self._lib = _lib.load()
         self.num_bodies = int(num_bodies)
         self.force_mode = "pair_once" if force_mode == "symmetric" else force_mode
         self.integrator, self.exchange, self.transport = integrator, exchange, transport
         cfg = _lib.MultiConfig(self.num_bodies, int(split_len), FORCE_MODES[force_mode], INTEGRATORS[integrator],
-                               EXCHANGES[exchange], TRANSPORTS[transport])
+                               EXCHANGES[exchange], TRANSPORTS[transport], _system.BODY_ORDERS.index(body_order), 0)
         m = ctypes.c_void_p(None)
         if _rank is None:
             devs = list(devices if devices is not None else [0])
@@ -182,12 +181,18 @@ class MultiGpuSystem:
 
     # -- buffers (kernel.cu:163-188) -----------------------------------------------------------------
     def _upload(self) -> None:
-        pos, vel = self._pos, self._vel
-        if self.body_order == "morton":  # a function of the positions: the same on every process
-            self.order = _system.morton_order(pos)
-            pos, vel = np.ascontiguousarray(pos[self.order]), np.ascontiguousarray(vel[self.order])
-        _check(self._lib.nbody_multi_set_state(self._m, pos.ctypes.data_as(ctypes.c_void_p),
-                                               vel.ctypes.data_as(ctypes.c_void_p)), self._m)
+        _check(self._lib.nbody_multi_set_state(self._m, self._pos.ctypes.data_as(ctypes.c_void_p),
+                                               self._vel.ctypes.data_as(ctypes.c_void_p)), self._m)
+
+    @property
+    def order(self):
+        """``order[k]`` = the caller's index of the body in slot ``k`` of the replicas (``nbody_multi_order``); ``None`` when
+        the bodies are stored as given."""
+        if self.body_order == "given":
+            return None
+        perm = np.empty(self.num_bodies, dtype=np.int64)
+        _check(self._lib.nbody_multi_order(self._m, perm.ctypes.data_as(ctypes.c_void_p)), self._m)
+        return perm
 
     def _rows(self, data) -> np.ndarray:
         a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
@@ -219,10 +224,6 @@ class MultiGpuSystem:
         e = np.ascontiguousarray(eps, dtype=np.float32).reshape(-1)
         if e.shape[0] != self.num_bodies:
             raise ValueError(f"expected {self.num_bodies} softening lengths, got {e.shape[0]}")
-        if self.body_order == "morton":
-            if self.order is None:
-                raise NBodyError(_lib.NBODY_ERR_STATE, "body_order='morton': set the positions before the softening lengths")
-            e = np.ascontiguousarray(e[self.order])
         _check(self._lib.nbody_multi_set_particle_softening(self._m, e.ctypes.data_as(ctypes.c_void_p)), self._m)
 
     def download(self) -> Tuple[np.ndarray, np.ndarray]:
@@ -231,10 +232,6 @@ class MultiGpuSystem:
         v = np.empty((self.num_bodies, 4), dtype=np.float32)
         _check(self._lib.nbody_multi_download(self._m, p.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)),
                self._m)
-        if self.order is not None:  # back to the caller's order
-            pc, vc = np.empty_like(p), np.empty_like(v)
-            pc[self.order], vc[self.order] = p, v
-            return pc, vc
         return p, v
 
     # -- the step (kernel.cu:1225-1242) ---------------------------------------------------------------
