@@ -22,7 +22,7 @@
 static void usage()
 {
     std::cerr << "usage: nbody_run [dataset_id 0-5] [--data-dir DIR] [--file PATH] [--plummer N] [--seed S] [--resume SNAPSHOT]\n"
-                 "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P] [--morton]\n"
+                 "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P] [--morton [--reorder-every M]]\n"
                  "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once] [--particle-softening]\n"
                  "                 [--devices D0,D1,...] [--ring] [--peer-copy]      rows sharded over several GPUs (library-owned exchange)\n";
 }
@@ -31,7 +31,7 @@ int main(int argc, char **argv)
 {
     int dataset = -1, device = 0;
     std::string data_dir = "./data", file, resume, dump_prefix = "nbody", final_path;
-    std::int64_t plummer_n = 0, steps = 100, energy_every = 0, dump_every = 0;
+    std::int64_t plummer_n = 0, steps = 100, energy_every = 0, dump_every = 0, reorder_every = 0;
     std::uint64_t seed = 0x5EED0003ull;
     float dt = nbody::kTimeTick, softening = nbody::kSofteningVersion3;  // the reference's constants
     bool pad = false, kdk = false, pair_once = false, particle_eps = false, ring = false, peer_copy = false, morton = false;
@@ -63,6 +63,7 @@ int main(int argc, char **argv)
         else if (a == "--ring") ring = true;
         else if (a == "--peer-copy") peer_copy = true;
         else if (a == "--morton") morton = true;
+        else if (a == "--reorder-every") reorder_every = std::atoll(next().c_str());  // with --morton --devices: refresh the layout
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-') {
             dataset = std::atoi(a.c_str());  // kernel.cu:1069-1086: argv[1] = dataset id, 0..5
@@ -109,6 +110,7 @@ int main(int argc, char **argv)
             nbody::MultiSystem ms;
             ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy, 0, morton);
             ms.setState(b.pos.data(), b.vel.data());
+            if (morton && reorder_every > 0) ms.setReorderPeriod(reorder_every);
             ms.timing(true);
             if (particle_eps) {
                 std::vector<float> eps((size_t)b.n());

@@ -76,7 +76,7 @@ int64_t nbody_n_total(const nbody_ctx *ctx);
  * sphere stored along a Morton curve instead of in random order runs its force pass 3.7 % faster, same instructions
  * (profiles/r02_body_order_force_pass.txt).  The reference draws whatever order its loader produced (kernel.cu:190-556);
  * order is not part of the physics.  nbody_morton_order fills perm[k] = the index, in the caller's arrays, of the body to
- * store at slot k: along a Morton curve (21 bits per axis over the bounding cube of the finite positions; ties by index),
+ * store at slot k: along a Morton curve (20 bits per axis over the bounding cube of the finite positions; ties by index),
  * and, when the set has at most NBODY_ORDER_MAX_SPECIES distinct masses, the bodies of one mass together in order of mass
  * (so that the splits of a few-species set each keep one mass -- the equal-mass inner loops -- wherever the species were
  * stored).  Deterministic; a pure function of the n float4 {x, y, z, m}.  The host layers apply it at upload and undo it
@@ -315,6 +315,14 @@ int nbody_multi_download(nbody_multi *m, float *host_xyzm, float *host_xyzw);
 /* perm[k] = the caller's index of the body stored in slot k of the replicas (the identity with NBODY_ORDER_GIVEN); n_bodies
  * entries, valid after nbody_multi_set_state.  A renderer that reads nbody_multi_positions_device sees this order. */
 int nbody_multi_order(nbody_multi *m, int64_t *perm);
+/* NBODY_ORDER_MORTON only (no-ops otherwise): the layout decays as the bodies move -- at N = 2^20 the first 100 steps of
+ * dt = 1e-3 run 4.2 % faster than in the generator's order, steps 900-1000 1.5 % (profiles/r02_longrun_morton_decay_*).
+ * nbody_multi_reorder lays a new curve through the current positions (state to the host and back: ~0.3 s at N = 2^20; the
+ * kick-drift-kick mode recomputes its cached accelerations); with a period > 0 the first step that is due does it by
+ * itself.  Results stay deterministic and the same for every rank count; they depend on the period (the order of the
+ * sums does).  Collective in the one-rank-per-process model. */
+int nbody_multi_reorder(nbody_multi *m);
+int nbody_multi_set_reorder_period(nbody_multi *m, int64_t steps);
 
 /* The step.  nbody_multi_step / _step_n return with every replica current and all device work complete;
  * nbody_multi_step_async only enqueues (the exchange of the updated rows stays in flight under the next step). */

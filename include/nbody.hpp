@@ -152,6 +152,8 @@ public:
         check(nbody_multi_set_particle_softening(m_, hostEps), "nbody_multi_set_particle_softening");
     }
     void download(float *xyzm, float *xyzw) { check(nbody_multi_download(m_, xyzm, xyzw), "nbody_multi_download"); }
+    void reorder() { check(nbody_multi_reorder(m_), "nbody_multi_reorder"); }  // mortonOrder: a new curve through the current positions
+    void setReorderPeriod(std::int64_t steps) { check(nbody_multi_set_reorder_period(m_, steps), "nbody_multi_set_reorder_period"); }
     void step(float dt = kTimeTick, float softening = kSofteningVersion3) { check(nbody_multi_step(m_, dt, softening), "nbody_multi_step"); }
     void stepN(int k, float dt, float softening) { check(nbody_multi_step_n(m_, k, dt, softening), "nbody_multi_step_n"); }
     System::Energy energy(float softening)

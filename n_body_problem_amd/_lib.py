@@ -78,6 +78,8 @@ _PROTOTYPES = {
     "nbody_set_summation_parts": (c_int, [c_void_p, c_int]),
     "nbody_morton_order": (c_int, [c_void_p, c_int64, c_void_p]),
     "nbody_multi_order": (c_int, [c_void_p, c_void_p]),
+    "nbody_multi_reorder": (c_int, [c_void_p]),
+    "nbody_multi_set_reorder_period": (c_int, [c_void_p, c_int64]),
     "nbody_partial_sum_bytes": (c_int64, [c_void_p]),
     "nbody_device_info": (c_int, [c_void_p, POINTER(c_int64), c_char_p, c_int]),
     # multi-GPU (csrc/nbody_multi.hip)

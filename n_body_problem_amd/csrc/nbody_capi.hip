@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -190,9 +191,9 @@ int nbody_morton_order(const float *xyzm, int64_t n, int64_t *perm)
     double extent = 0.0;
     for (int a = 0; a < 3; ++a)
         extent = std::max(extent, (double)hi[a] - (double)lo[a]);
-    const double scale = extent > 0.0 ? 2097151.0 / extent : 0.0;  // 21 bits per axis
+    const double scale = extent > 0.0 ? 1048575.0 / extent : 0.0;  // 20 bits per axis
     auto spread = [](uint64_t v) {  // bit k of v to bit 3k
-        v &= 0x1fffffull;
+        v &= 0xfffffull;
         v = (v | v << 32) & 0x1f00000000ffffull;
         v = (v | v << 16) & 0x1f0000ff0000ffull;
         v = (v | v << 8) & 0x100f00f00f00f00full;
@@ -203,9 +204,15 @@ int nbody_morton_order(const float *xyzm, int64_t n, int64_t *perm)
     // few species: the mass first (rank of the mass among the distinct values), then the curve
     std::vector<uint32_t> species;
     bool few = true;
+    uint32_t last_bits = 0;
+    bool have_last = false;
     for (int64_t i = 0; i < n && few; ++i) {
         uint32_t bits;
         std::memcpy(&bits, xyzm + 4 * i + 3, 4);
+        if (have_last && bits == last_bits)
+            continue;
+        last_bits = bits;
+        have_last = true;
         if (std::find(species.begin(), species.end(), bits) == species.end()) {
             species.push_back(bits);
             few = species.size() <= NBODY_ORDER_MAX_SPECIES;
@@ -218,27 +225,68 @@ int nbody_morton_order(const float *xyzm, int64_t n, int64_t *perm)
             std::memcpy(&fb, &b, 4);
             return fa < fb || (!(fb < fa) && a < b);  // by value; NaNs and signed zeros by bit pattern
         });
-    struct Key { uint64_t curve; uint32_t species; int64_t index; };
-    std::vector<Key> keys((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        const float *p = xyzm + 4 * i;
-        uint64_t q[3] = {0, 0, 0};
-        const bool finite = std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
-        for (int a = 0; a < 3 && finite; ++a)
-            q[a] = (uint64_t)std::min(2097151.0, std::max(0.0, ((double)p[a] - (double)lo[a]) * scale));
-        uint32_t bits, rank = 0;
-        std::memcpy(&bits, p + 3, 4);
-        if (few)
-            rank = (uint32_t)(std::find(species.begin(), species.end(), bits) - species.begin());
-        keys[(size_t)i] = Key{finite ? (spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2) : ~0ull, rank, i};
-    }
-    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-        if (a.species != b.species) return a.species < b.species;
-        if (a.curve != b.curve) return a.curve < b.curve;
-        return a.index < b.index;
+    // key = species rank (4 bits) | curve (60 bits); bodies without a finite position last within their species.
+    // Host threads over contiguous chunks (a refresh of the layout costs a run as much as this function takes).
+    const int threads = (int)std::max<int64_t>(1, std::min<int64_t>({8, (int64_t)std::thread::hardware_concurrency(), n / 65536}));
+    auto chunk = [&](int t) { return std::make_pair(n * t / threads, n * (t + 1) / threads); };
+    auto in_parallel = [&](auto &&body) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t)
+            pool.emplace_back(body, t);
+        body(0);
+        for (auto &th : pool)
+            th.join();
+    };
+    std::vector<uint64_t> keys((size_t)n), keys2((size_t)n);
+    std::vector<int64_t> idx2((size_t)n);
+    in_parallel([&](int t) {
+        for (int64_t i = chunk(t).first; i < chunk(t).second; ++i) {
+            const float *p = xyzm + 4 * i;
+            const bool finite = std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
+            uint64_t curve = (1ull << 60) - 1;
+            if (finite) {
+                uint64_t q[3];
+                for (int a = 0; a < 3; ++a)
+                    q[a] = (uint64_t)std::min(1048575.0, std::max(0.0, ((double)p[a] - (double)lo[a]) * scale));
+                curve = spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2;
+            }
+            uint64_t rank = 0;
+            if (few) {
+                uint32_t bits;
+                std::memcpy(&bits, p + 3, 4);
+                rank = (uint64_t)(std::find(species.begin(), species.end(), bits) - species.begin());
+            }
+            keys[(size_t)i] = rank << 60 | curve;
+            perm[i] = i;
+        }
     });
-    for (int64_t k = 0; k < n; ++k)
-        perm[k] = keys[(size_t)k].index;
+    // stable LSD radix sort, 16 bits a pass (ties keep the caller's order): per-thread histograms, then every thread
+    // scatters its chunk behind the chunks before it
+    std::vector<std::vector<int64_t>> count((size_t)threads, std::vector<int64_t>(65536));
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 16 * pass;
+        in_parallel([&](int t) {
+            std::fill(count[(size_t)t].begin(), count[(size_t)t].end(), 0);
+            for (int64_t i = chunk(t).first; i < chunk(t).second; ++i)
+                ++count[(size_t)t][(size_t)((keys[(size_t)i] >> shift) & 0xffff)];
+        });
+        int64_t at = 0;
+        for (size_t d = 0; d < 65536; ++d)
+            for (int t = 0; t < threads; ++t) {
+                const int64_t c = count[(size_t)t][d];
+                count[(size_t)t][d] = at;
+                at += c;
+            }
+        in_parallel([&](int t) {
+            for (int64_t i = chunk(t).first; i < chunk(t).second; ++i) {
+                const int64_t to = count[(size_t)t][(size_t)((keys[(size_t)i] >> shift) & 0xffff)]++;
+                keys2[(size_t)to] = keys[(size_t)i];
+                idx2[(size_t)to] = perm[i];
+            }
+        });
+        keys.swap(keys2);
+        std::memcpy(perm, idx2.data(), sizeof(int64_t) * (size_t)n);
+    }
     return NBODY_OK;
 }
 

@@ -69,6 +69,9 @@ struct nbody_multi {
     std::vector<Rank> ranks;  // the local ranks
     Channel ch_pos, ch_col;
     std::vector<int64_t> order;  // NBODY_ORDER_MORTON: slot k of the replicas holds the caller's body order[k] (set by set_state)
+    std::vector<float> eps_caller;             // the per-particle softening lengths as given (the caller's order), or empty
+    bool eps_on = false;
+    int64_t reorder_period = 0, steps_since_order = 0;  // NBODY_ORDER_MORTON: refresh the layout every so many steps (0: never)
     bool exchange_in_flight = false;  // the position exchange of the last update has been issued and not yet consumed
     bool kdk_ready = false;
     bool have_state = false;
@@ -858,18 +861,31 @@ static int settle(nbody_multi *m)
     return rc;
 }
 
+// The layout decays as the bodies move (N = 2^20 Plummer sphere: half of the gain is gone after ~300 steps of dt = 1e-3,
+// profiles/r02_longrun_morton_decay_n1048576.txt): with a reorder period the step that is due first refreshes it.
+static int reorder_if_due(nbody_multi *m)
+{
+    if (m->reorder_period > 0 && m->cfg.body_order == NBODY_ORDER_MORTON && m->steps_since_order >= m->reorder_period)
+        return nbody_multi_reorder(m);
+    return NBODY_OK;
+}
+
 extern "C" int nbody_multi_step_async(nbody_multi *m, float dt, float softening)
 {
     if (!m)
         return NBODY_ERR_INVALID;
-    return step_async(m, dt, softening);
+    int rc = reorder_if_due(m);
+    if (rc == NBODY_OK)
+        rc = step_async(m, dt, softening);
+    m->steps_since_order += rc == NBODY_OK;
+    return rc;
 }
 
 extern "C" int nbody_multi_step(nbody_multi *m, float dt, float softening)
 {
     if (!m)
         return NBODY_ERR_INVALID;
-    int rc = step_async(m, dt, softening);
+    int rc = nbody_multi_step_async(m, dt, softening);
     return rc == NBODY_OK ? settle(m) : rc;
 }
 
@@ -881,9 +897,12 @@ extern "C" int nbody_multi_step_n(nbody_multi *m, int k, float dt, float softeni
         const int slot = s % kStepsInFlight;
         int rc = s >= kStepsInFlight ? wait_step(m, slot) : NBODY_OK;  // step s - kStepsInFlight has finished
         if (rc == NBODY_OK)
+            rc = reorder_if_due(m);
+        if (rc == NBODY_OK)
             rc = step_async(m, dt, softening);
         if (rc != NBODY_OK)
             return rc;
+        ++m->steps_since_order;
         for (Rank &r : m->ranks) {
             MHIP(m, hipSetDevice(r.device));
             MHIP(m, hipEventRecord(r.ev_step[(size_t)slot], r.compute));
@@ -893,6 +912,8 @@ extern "C" int nbody_multi_step_n(nbody_multi *m, int k, float dt, float softeni
 }
 
 // ---- state in and out ------------------------------------------------------------------------------------------------
+
+static int upload_softening(nbody_multi *m);
 
 extern "C" int nbody_multi_set_state(nbody_multi *m, const float *host_pos, const float *host_vel)
 {
@@ -928,6 +949,31 @@ extern "C" int nbody_multi_set_state(nbody_multi *m, const float *host_pos, cons
     }
     m->kdk_ready = false;
     m->have_state = true;
+    m->steps_since_order = 0;
+    if (m->eps_on && m->cfg.body_order == NBODY_ORDER_MORTON)
+        return upload_softening(m);  // the lengths follow their bodies to the new slots
+    return NBODY_OK;
+}
+
+static int upload_softening(nbody_multi *m)  // m->eps_caller (the caller's order, or empty) in the order of the replicas
+{
+    std::vector<float> eps;
+    const bool on = !m->eps_caller.empty() || (m->eps_on && m->n_bodies == 0);
+    if (on) {
+        eps.assign((size_t)m->n_padded, 0.f);
+        if (m->cfg.body_order == NBODY_ORDER_MORTON && m->n_bodies) {
+            if (m->order.size() != (size_t)m->n_bodies)
+                return mfail(m, NBODY_ERR_STATE, "nbody_multi_set_particle_softening: with NBODY_ORDER_MORTON call "
+                                                 "nbody_multi_set_state first (the order is a function of the positions)");
+            for (int64_t k = 0; k < m->n_bodies; ++k)
+                eps[(size_t)k] = m->eps_caller[(size_t)m->order[(size_t)k]];
+        } else if (m->n_bodies) {
+            std::memcpy(eps.data(), m->eps_caller.data(), sizeof(float) * (size_t)m->n_bodies);
+        }
+    }
+    for (Rank &r : m->ranks)
+        MCTX(m, r, nbody_upload_particle_softening(r.ctx, on ? eps.data() : nullptr));
+    m->kdk_ready = false;
     return NBODY_OK;
 }
 
@@ -938,23 +984,37 @@ extern "C" int nbody_multi_set_particle_softening(nbody_multi *m, const float *h
     int rc = settle(m);
     if (rc != NBODY_OK)
         return rc;
-    std::vector<float> eps;
-    if (host_eps) {
-        eps.assign((size_t)m->n_padded, 0.f);
-        if (m->cfg.body_order == NBODY_ORDER_MORTON) {
-            if (m->order.size() != (size_t)m->n_bodies)
-                return mfail(m, NBODY_ERR_STATE, "nbody_multi_set_particle_softening: with NBODY_ORDER_MORTON call "
-                                                 "nbody_multi_set_state first (the order is a function of the positions)");
-            for (int64_t k = 0; k < m->n_bodies; ++k)
-                eps[(size_t)k] = host_eps[(size_t)m->order[(size_t)k]];
-        } else {
-            std::memcpy(eps.data(), host_eps, sizeof(float) * (size_t)m->n_bodies);
-        }
-    }
-    for (Rank &r : m->ranks)
-        MCTX(m, r, nbody_upload_particle_softening(r.ctx, host_eps ? eps.data() : nullptr));
-    m->kdk_ready = false;
+    m->eps_on = host_eps != nullptr;
+    if (host_eps)
+        m->eps_caller.assign(host_eps, host_eps + m->n_bodies);
+    else
+        m->eps_caller.clear();
+    return upload_softening(m);
+}
+
+extern "C" int nbody_multi_set_reorder_period(nbody_multi *m, int64_t steps)
+{
+    if (!m || steps < 0)
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_reorder_period: steps must be >= 0");
+    m->reorder_period = steps;
     return NBODY_OK;
+}
+
+extern "C" int nbody_multi_reorder(nbody_multi *m)
+{
+    if (!m)
+        return NBODY_ERR_INVALID;
+    if (m->cfg.body_order != NBODY_ORDER_MORTON || !m->have_state || !m->n_bodies) {
+        m->steps_since_order = 0;
+        return NBODY_OK;  // nothing to refresh
+    }
+    std::vector<float> pos(4 * (size_t)m->n_bodies), vel(4 * (size_t)m->n_bodies);
+    int rc = nbody_multi_download(m, pos.data(), vel.data());  // the caller's order; collective in the one-rank-per-process model
+    if (rc == NBODY_OK)
+        rc = nbody_multi_set_state(m, pos.data(), vel.data());  // a new curve through the current positions
+    if (rc == NBODY_OK && m->eps_on)
+        rc = upload_softening(m);
+    return rc;
 }
 
 static int download_device_order(nbody_multi *m, float *host_pos, float *host_vel);

@@ -184,6 +184,14 @@ class MultiGpuSystem:
         _check(self._lib.nbody_multi_set_state(self._m, self._pos.ctypes.data_as(ctypes.c_void_p),
                                                self._vel.ctypes.data_as(ctypes.c_void_p)), self._m)
 
+    def reorder(self) -> None:
+        """``body_order="morton"``: a new curve through the current positions (the layout decays as the bodies move)."""
+        _check(self._lib.nbody_multi_reorder(self._m), self._m)
+
+    def set_reorder_period(self, steps: int) -> None:
+        """Refresh the layout by itself every ``steps`` steps (0: never)."""
+        _check(self._lib.nbody_multi_set_reorder_period(self._m, int(steps)), self._m)
+
     @property
     def order(self):
         """``order[k]`` = the caller's index of the body in slot ``k`` of the replicas (``nbody_multi_order``); ``None`` when

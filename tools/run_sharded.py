@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--body-order", default="given", choices=["given", "morton"],
                     help="morton: the library stores the bodies along a Morton curve (3-4 %% more clock); nccl backend only")
+    ap.add_argument("--reorder-every", type=int, default=0, help="with --body-order morton: refresh the layout every so many steps")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
@@ -54,6 +55,8 @@ def main():
                        split_len=args.split_len, body_order=args.body_order)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel)
+    if args.reorder_every and hasattr(s, "set_reorder_period"):
+        s.set_reorder_period(args.reorder_every)
     del pos, vel
     e0 = s.energy(args.softening)
     if rank == 0:
