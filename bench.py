@@ -196,6 +196,13 @@ def committed_traffic(n, kernel):
     return best
 
 
+def forwarded_args(argv):
+    """The command line as the rank processes get it behind torch.distributed.run: argparse checks every "--x" on the line
+    against the launcher's own options before it reaches the script's, and "--n" is an ambiguous prefix there ("--nnodes",
+    "--nproc-per-node", ...); its alias "--bodies" is not."""
+    return ["--bodies" if a == "--n" else "--bodies=" + a[4:] if a.startswith("--n=") else a for a in argv]
+
+
 def launch_ranks(args):
     """--gpus N without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) from a parent that
     never touches a GPU, relay their output and return the exit code -- non-zero when fewer than N devices are visible,
@@ -210,8 +217,9 @@ def launch_ranks(args):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    forwarded = forwarded_args(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *forwarded]
     log("bench.py: launching", " ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
     line = None
