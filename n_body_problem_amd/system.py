@@ -80,6 +80,7 @@ class NBodySystem:
             raise ValueError(f"body_order must be one of {BODY_ORDERS}")
         self.body_order = body_order
         self.order = None       # the permutation in use (set by setParticlesPosition)
+        self._reorder_period, self._steps_since_order = 0, 0
         self._ctx = ctypes.c_void_p(None)
         self._lib = _lib.load()
         torch = _torch()
@@ -135,6 +136,7 @@ class NBodySystem:
         if self.body_order == "morton":
             self.order = morton_order(a)
             a = np.ascontiguousarray(a[self.order])
+            self._steps_since_order = 0
         self.positions.copy_(torch.from_numpy(a))
         self._lib.nbody_invalidate_forces(self._ctx)
 
@@ -157,9 +159,17 @@ class NBodySystem:
     set_particles_position = setParticlesPosition
     set_particles_velocity = setParticlesVelocity
 
+    def set_reorder_period(self, steps: int) -> None:
+        """``body_order="morton"``: :meth:`step_n` refreshes the layout by itself every ``steps`` steps (0: never) -- the
+        same schedule as ``nbody_multi_set_reorder_period``, so a single context and shards keep producing the same bits."""
+        if steps < 0:
+            raise ValueError("steps must be >= 0")
+        self._reorder_period = int(steps)
+
     def reorder(self) -> None:
         """``body_order="morton"``: a new curve through the current positions (the layout decays as the bodies move: at
         N = 2^20 half of the gain is gone after ~300 steps of dt = 1e-3).  State to the host and back."""
+        self._steps_since_order = 0
         if self.body_order != "morton" or self.order is None:
             return
         pos, vel = self.download()
@@ -189,6 +199,9 @@ class NBodySystem:
         ``masses`` (optional device tensor of ``num_bodies`` floats) is first copied into
         ``positions[:,3]``; the default, as in the reference, is that mass already lives there."""
         self._use_current_stream()
+        if self._reorder_period > 0 and self.body_order == "morton" and self._steps_since_order >= self._reorder_period:
+            self.reorder()
+        self._steps_since_order += 1
         fn = self._lib.nbody_step if sync else self._lib.nbody_step_async
         if masses is not None and self.order is not None:
             masses = masses.reshape(-1)[_torch().from_numpy(self.order).to(self.device)].contiguous()
@@ -199,8 +212,18 @@ class NBodySystem:
         """``k`` steps enqueued back to back, one synchronisation at the end (``nbody_step_n_on``: small systems replay a
         captured HIP graph of one step, see :meth:`set_graph_replay`)."""
         self._use_current_stream()
-        check(self._lib.nbody_step_n_on(self._ctx, _ptr(self.positions), _ptr(self.velocities), int(k), float(dt),
-                                        float(softening)), self._ctx)
+        k = int(k)
+        if k <= 0:
+            check(self._lib.nbody_step_n_on(self._ctx, _ptr(self.positions), _ptr(self.velocities), k, float(dt),
+                                            float(softening)), self._ctx)
+        while k > 0:
+            if self._reorder_period > 0 and self.body_order == "morton" and self._steps_since_order >= self._reorder_period:
+                self.reorder()
+            run = k if self._reorder_period <= 0 or self.body_order != "morton" else min(k, self._reorder_period - self._steps_since_order)
+            check(self._lib.nbody_step_n_on(self._ctx, _ptr(self.positions), _ptr(self.velocities), run, float(dt),
+                                            float(softening)), self._ctx)
+            self._steps_since_order += run
+            k -= run
 
     def set_graph_replay(self, mode: int) -> None:
         """-1: automatic (pair-once mode up to 32 768 bodies, where the replay measured faster), 0: never, 1: always."""

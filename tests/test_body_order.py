@@ -147,7 +147,7 @@ def test_reorder_refreshes_the_layout_and_keeps_the_physics(integrator):
     reorder calls made by hand, bit for bit; against a run without refresh the state differs by rounding only; and two
     shards do what one does."""
     from n_body_problem_amd.multi import MultiGpuSystem
-    n = 20000
+    n = 20480                                                   # 80 splits of 256: no padding in the pair-once geometry
     pos, vel = nb.plummer(n, seed=12)
     eps = np.random.default_rng(4).uniform(0.0, 0.02, n).astype(np.float32)
     out = {}
@@ -175,6 +175,20 @@ def test_reorder_refreshes_the_layout_and_keeps_the_physics(integrator):
                 assert np.array_equal(np.sort(m.order), np.arange(n))
             if how == "never":
                 assert np.array_equal(m.order, first)
+    with MultiGpuSystem(n, devices=[0], force_mode="pair_once", integrator=integrator, transport="peer_copy") as probe:
+        split_len, n_padded = probe.split_len, probe.n_padded
+    assert n_padded == n
+    if True:                                                    # the Python layer's period keeps the library's schedule
+        with nb.NBodySystem(n, split_len=split_len, body_order="morton") as s:
+            s.set_force_mode("pair_once")
+            s.set_integrator(integrator)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            s.set_particle_softening(eps)
+            s.set_reorder_period(4)
+            s.step_n(10, 5e-3, 1e-3)
+            out["python layer"] = s.download()
+        assert np.array_equal(out["period"][0], out["python layer"][0]) and np.array_equal(out["period"][1], out["python layer"][1])
     for a in ("by hand", "two shards"):
         assert np.array_equal(out["period"][0], out[a][0]) and np.array_equal(out["period"][1], out[a][1]), a
     assert np.array_equal(out["period"][0][:, 3], pos[:, 3]) and np.array_equal(out["period"][1][:, 3], vel[:, 3])
