@@ -109,15 +109,18 @@ def main():
         Lm = L if (mode == "pair_once" and L <= 4096) or mode == "one_sided" else 1024
         vel = (rng.normal(size=(n, 4)) * 0.1).astype(np.float32)
         from n_body_problem_amd.multi import MultiGpuSystem
+        order = str(rng.choice(["given", "morton"]))             # the library stores the bodies along a Morton curve
         with MultiGpuSystem(n, devices=[0] * world, force_mode=mode, integrator=integrator, exchange=exchange,
-                            transport="peer_copy", split_len=Lm) as m:
+                            transport="peer_copy", split_len=Lm, body_order=order) as m:
             m.set_state(pos, vel)
             m.step_n(2, 1e-3, eps)
             got = m.download()
             assert m.replicas_identical()
             n_padded = m.n_padded
         pp, vv = np.zeros((n_padded, 4), np.float32), np.zeros((n_padded, 4), np.float32)
-        pp[:n], vv[:n] = pos, vel
+        perm = nb.morton_order(pos) if order == "morton" else np.arange(n)
+        pp[:n], vv[:n] = pos[perm], vel[perm]
+        got = (got[0][perm], got[1][perm])
         with nb.NBodySystem(n_padded, split_len=Lm) as s:
             s.set_force_mode(mode)
             s.set_integrator(integrator)
@@ -127,7 +130,7 @@ def main():
             want = s.download()
         assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (case, mode, world, exchange, integrator, n, Lm)
         print(f"case {case:3d}: n={n:6d} split_len={L:5d} eps={eps:g} masses {pattern:7s} ok (pair vs one {d:.1e}); "
-              f"{world} shards {mode} {exchange} {integrator} = one context", flush=True)
+              f"{world} shards {mode} {exchange} {integrator} {order} order = one context", flush=True)
     print("worst relative differences:", {k: float(f"{v:.3e}") for k, v in worst.items()})
 
 
