@@ -149,6 +149,7 @@ int nbody_update(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xy
  *   nbody_forces (+ _complement) -> nbody_kdk_kick. */
 enum { NBODY_INTEGRATOR_KICK_DRIFT = 0, NBODY_INTEGRATOR_KDK = 1 };
 int nbody_set_integrator(nbody_ctx *ctx, int integrator);
+/* Forgets the cached accelerations and every partial sum nbody_forces has produced since the last update. */
 int nbody_invalidate_forces(nbody_ctx *ctx);
 int nbody_kdk_prepare(nbody_ctx *ctx);
 int nbody_kdk_kick_drift(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, float dt);

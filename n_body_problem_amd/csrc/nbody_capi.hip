@@ -1205,6 +1205,7 @@ int nbody_invalidate_forces(nbody_ctx *c)
     if (!c)
         return NBODY_ERR_INVALID;
     c->acc_valid = false;
+    std::fill(c->split_done.begin(), c->split_done.end(), 0);  // partial sums of other positions are no partial sums
     return NBODY_OK;
 }
 
