@@ -203,7 +203,7 @@ enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
  * still fit one GPU even in one summation part (nbody_set_summation_parts; a single context holds a quarter by default). */
 int64_t nbody_pair_once_split_len(int64_t n_total);
 #define NBODY_SYM_GROUPS 8
-#define NBODY_DEFAULT_SUMMATION_PARTS 8
+#define NBODY_PARTIAL_SUM_BUDGET_BYTES (4ll << 30) /* nbody_set_summation_parts(ctx, 0): the fewest parts that stay below */
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 /* The exchange buffer of the pair-once mode: NBODY_SYM_GROUPS x n_total x float4 on the device, group-major.
  * d_buf is borrowed (NULL: a buffer the context owns -- enough for a single context).  nbody_sym_reduce writes the
@@ -243,7 +243,9 @@ int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
  * groups either way).  parts = 1: one launch, then the whole summation.  2: every group but the last, then the last (one
  * extra launch tail; the partial-sum arrays hold the whole pass: n^2 / split_len 12-byte entries, 12.9 GB at N = 2^20).
  * 4, 8: equal parts whose arrays live in two slots used in turn: 2/parts of that (8 parts: 3.2 GB at N = 2^20, 19 GB at
- * 2^22), for one launch tail (~0.2 ms) per extra part (measured at N = 2^20: 8 parts cost ~1 % of the step against 1).  0: the default (NBODY_DEFAULT_SUMMATION_PARTS).  Systems too small
+ * 2^22), for one launch tail (~0.2 ms) per extra part (measured at N = 2^20: 8 parts cost ~1 % of the step against 1).  0, the default: automatic -- one launch while the whole
+ * pass fits NBODY_PARTIAL_SUM_BUDGET_BYTES (4 GiB: up to N = 589 000 with 1024-body splits), else 4 parts if a half
+ * does, else 8 (N = 2^20: 8 parts, 3.2 GB; N = 2^22: 8 parts, 19 GB).  Systems too small
  * for several launches, shards and column-range calls always take one part.  nbody_set_early_summation(on) is
  * nbody_set_summation_parts(on ? 0 : 1). */
 int nbody_set_summation_parts(nbody_ctx *ctx, int parts);

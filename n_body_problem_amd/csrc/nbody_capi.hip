@@ -106,7 +106,6 @@ static int fail(nbody_ctx *c, int status, const std::string &msg)
 }
 
 static void free_sym_tiles(nbody_ctx *c);
-static constexpr int kDefaultSumParts = NBODY_DEFAULT_SUMMATION_PARTS;  // see forces_impl; measured in profiles/r02_summation_parts.txt
 
 #define HIP_TRY(c, call)                                                                                   \
     do {                                                                                                   \
@@ -954,7 +953,11 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             // the force pass is the last part's share of the summation and the combination.  2 parts = 7 groups + 1 (one
             // extra launch tail, the arrays hold the whole pass); 4 or 8 equal parts keep two parts' arrays.
             const int n_groups = (S + c->group_splits - 1) / c->group_splits;
-            int K = c->sum_parts ? c->sum_parts : kDefaultSumParts;
+            int K = c->sum_parts;
+            if (K == 0) {  // automatic: one launch is the fastest (profiles/r02_summation_parts_eight_rows.txt); more only for memory
+                const double pass_bytes = 12.0 * (double)c->n_total * (double)c->n_total / (double)L;
+                K = pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 1 : pass_bytes / 2 <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 4 : 8;
+            }
             // below 32768 tiles (N = 2^18) an extra launch costs more than the summation it hides; the variable is for tests
             const char *min_env = getenv("NBODY_SYM_PARTS_MIN_TILES");
             const int64_t min_tiles = min_env ? atoll(min_env) : 32768;
