@@ -196,11 +196,12 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
  * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
 /* The split length to create a pair-once context with.  A function of n_total ONLY (split boundaries define the
- * summation order, so they must not depend on the sharding): 1024 from 204 800 to 2^21 bodies -- the kernel's rows per
+ * summation order, so they must not depend on the sharding): 1024 from 204 800 bodies up -- the kernel's rows per
  * pass, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles below that (small systems
- * need more, smaller tiles to fill the chip), then 2048 (N = 2^22) and 4096, so that the partial sums
- * of one pass (n_total^2 / split_len entries of 12 bytes over all contexts: 12.9 GB at N = 2^20, 77 GB at N = 2^22) would
- * still fit one GPU even in one summation part (nbody_set_summation_parts; a single context holds a quarter by default). */
+ * need more, smaller tiles to fill the chip), 2048 from N = 2^20 (half the partial sums: 2.2 % faster at equal memory)
+ * and 4096 from 2^23, so that the partial sums of one pass (n_total^2 / split_len entries of 12 bytes over all contexts:
+ * 6.4 GB at N = 2^20, 103 GB at N = 2^22) would still fit one GPU even in one summation part
+ * (nbody_set_summation_parts; by default a single context holds 3.2 GB and 26 GB of them). */
 int64_t nbody_pair_once_split_len(int64_t n_total);
 #define NBODY_SYM_GROUPS 8
 #define NBODY_PARTIAL_SUM_BUDGET_BYTES (4ll << 30) /* nbody_set_summation_parts(ctx, 0): the fewest parts that stay below */
@@ -241,11 +242,12 @@ int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
  * tiles run an auxiliary stream already forms the sums of the part before it: only the last part's share of the
  * summation and the combination stay behind the force pass.  The result does not change by a bit (the association is by
  * groups either way).  parts = 1: one launch, then the whole summation.  2: every group but the last, then the last (one
- * extra launch tail; the partial-sum arrays hold the whole pass: n^2 / split_len 12-byte entries, 12.9 GB at N = 2^20).
- * 4, 8: equal parts whose arrays live in two slots used in turn: 2/parts of that (8 parts: 3.2 GB at N = 2^20, 19 GB at
- * 2^22), for one launch tail (~0.2 ms) per extra part (measured at N = 2^20: 8 parts cost ~1 % of the step against 1).  0, the default: automatic -- one launch while the whole
+ * extra launch tail; the partial-sum arrays hold the whole pass: n^2 / split_len 12-byte entries, 6.4 GB at N = 2^20).
+ * 4, 8: equal parts whose arrays live in two slots used in turn: 2/parts of that (4 parts: 3.2 GB at N = 2^20; 8 parts:
+ * 26 GB at 2^22), for one launch tail (0.2-0.5 ms) per extra part (measured at N = 2^20 with 1024-body splits: 8 parts
+ * cost ~1 % of the step against 1).  0, the default: automatic -- one launch while the whole
  * pass fits NBODY_PARTIAL_SUM_BUDGET_BYTES (4 GiB: up to N = 589 000 with 1024-body splits), else 4 parts if a half
- * does, else 8 (N = 2^20: 8 parts, 3.2 GB; N = 2^22: 8 parts, 19 GB).  Systems too small
+ * does, else 8 (N = 2^20: 4 parts, 3.2 GB; N = 2^22: 8 parts, 26 GB).  Systems too small
  * for several launches, shards and column-range calls always take one part.  nbody_set_early_summation(on) is
  * nbody_set_summation_parts(on ? 0 : 1). */
 int nbody_set_summation_parts(nbody_ctx *ctx, int parts);

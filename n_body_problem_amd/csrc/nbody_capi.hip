@@ -151,20 +151,23 @@ int64_t nbody_default_split_len(int64_t n_total)
 
 int64_t nbody_pair_once_split_len(int64_t n_total)
 {
-    // 1024 = the pair-once kernel's rows per pass (4 waves x 64 lanes x 4 rows): shorter splits idle waves, longer ones
-    // coarsen the grid (at N = 2^20 one of 8 ranks measured 24.4 ms per step with 1024, 25.8 with 2048, 46.9 with 512;
-    // N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms; 4096 leaves 3 workgroups per CU: 441 against 392 ms for one of 8 ranks
-    // at N = 2^22).  One pass writes n_total^2 / split_len partial sums of 12 bytes into the two arrays: 12.9 GB at
-    // N = 2^20 (a single context holds two of its eight summation parts at a time, 3.2 GB); the length doubles where
-    // 16-byte entries (round 1's layout: the rule is kept, split boundaries define the summation order) would pass
-    // 150 GB -- 2048 at N = 2^22: 77 GB per pass, one GPU can still hold it whole.
+    // 1024 = the eight-row kernel's rows per pass with two waves (four-row kernel: four waves): shorter splits idle waves,
+    // longer ones coarsen the grid (N = 131072 on one GPU 3.6 / 4.6 / 6.2 ms with 1024 / 2048 / 512).  One pass writes
+    // n_total^2 / split_len partial sums of 12 bytes into the two arrays: from N = 2^20 on the splits are 2048 bodies -- half
+    // the partial sums (6.4 GB per pass at N = 2^20, held in 4 summation parts of which two exist at a time: 3.2 GB) and
+    // 2.2 % less time per step than 1024-body splits in 8 parts at the same memory (156.0 against 159.5 ms, one GPU; one
+    // rank of 8: 19.7 against 20.0 ms; profiles/r02_split_len_auto_parts_sustained.txt, r02_shard_rate_eight_rows_split_len.txt);
+    // at N = 524288 one rank of 8 would lose 5 % to 2048 (a quarter of the tiles per rank), so 1024 stays below 2^20.
+    // The length doubles again where 16-byte entries (round 1's layout: the bound is kept) would pass 150 GB: 4096 from
+    // N = 2^23 (N = 2^22: 2048, 103 GB per pass, 26 GB held).  A function of n_total only: split boundaries define the
+    // summation order.
     // Below ~200 000 bodies 1024-body tiles are too few to fill 256 CUs x 5 workgroups evenly (N = 131072: 2016 tiles):
     // the splits shrink to n_total / 200, in whole 256-body tiles, and the tile kernel runs with 2 or 1 wave per workgroup.
     const double pairs16 = 16.0 * (double)n_total * (double)n_total;
     int64_t len = n_total / 200 / kTile * kTile;
     if (len < 1024)
         return len < kTile ? kTile : len;
-    len = 1024;
+    len = n_total >= ((int64_t)1 << 20) ? 2048 : 1024;
     while (len < 4096 && pairs16 / (double)len > 150e9)
         len *= 2;
     return len;

@@ -27,7 +27,7 @@ def test_geometry_matches_the_rehearsal_harness_and_keeps_whole_groups():
                 assert (padded, chunk) == sharded.pair_once_geometry(n, world, ps) and got == ps
                 group = padded // 8                       # a rank owns whole groups of ceil(n_splits / 8) splits
                 assert chunk % group == 0 and group % ps == 0 and chunk * world == padded >= n
-    assert multi.geometry(1 << 20, 8, "pair_once") == (1 << 20, 131072, 1024)      # BASELINE configs[3]
+    assert multi.geometry(1 << 20, 8, "pair_once") == (1 << 20, 131072, 2048)      # BASELINE configs[3]
     assert multi.geometry(1 << 22, 8, "pair_once") == (1 << 22, 524288, 2048)      # BASELINE configs[4]
     assert multi.geometry(1000, 2, split_len=256) == (1024, 512, 256)
     with pytest.raises(ValueError):

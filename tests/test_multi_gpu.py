@@ -203,7 +203,7 @@ def test_a_step_that_outlasts_the_timeout_is_reported_not_waited_for():
 
 @pytest.mark.parametrize("force_mode", ["pair_once", "one_sided"])
 def test_headline_size_two_shards_on_one_gpu_equal_one_context(oracle_mod, force_mode):
-    """BASELINE configs[2]/[3] at the headline size: N = 2^20, the pair-once mode with 1024-body splits (what bench.py
+    """BASELINE configs[2]/[3] at the headline size: N = 2^20, the pair-once mode with 2048-body splits (what bench.py
     runs), as one context and as two shards with the library-owned exchange: the same bits; the accelerations of sampled
     rows agree with the fp64 oracle and the total force vanishes."""
     import n_body_problem_amd as nb
@@ -211,7 +211,7 @@ def test_headline_size_two_shards_on_one_gpu_equal_one_context(oracle_mod, force
     n, steps = 1 << 20, 2
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
     with MultiGpuSystem(n, devices=[0, 0], force_mode=force_mode, transport="peer_copy") as m:
-        assert m.split_len == (1024 if force_mode == "pair_once" else 8192) and m.n_padded == n and m.chunk == n // 2
+        assert m.split_len == (2048 if force_mode == "pair_once" else 8192) and m.n_padded == n and m.chunk == n // 2
         m.set_state(pos, vel)
         m.step_n(steps, DT, EPS)
         p, v = m.download()
