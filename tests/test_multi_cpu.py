@@ -75,6 +75,7 @@ def test_bad_configurations_are_rejected_before_any_device_work():
            (_lib.MultiConfig(1000, 100, 0, 0, 0, 0), 2),    # split_len not a multiple of 256
            (_lib.MultiConfig(1000, 0, 7, 0, 0, 0), 2),      # unknown force mode
            (_lib.MultiConfig(1000, 0, 0, 0, 5, 0), 2),      # unknown exchange
+           (_lib.MultiConfig(1000, 0, 0, 0, 0, 0, 2, 0), 2),  # unknown body order
            (_lib.MultiConfig(-1, 0, 0, 0, 0, 0), 2)]
     for cfg, n in bad:
         assert lib.nbody_multi_create(ctypes.byref(m), ctypes.byref(cfg), dev, n) == _lib.NBODY_ERR_INVALID
@@ -84,6 +85,8 @@ def test_bad_configurations_are_rejected_before_any_device_work():
     assert lib.nbody_multi_create_rank(ctypes.byref(m), ctypes.byref(cfg), 0, 5, 2, ident) == _lib.NBODY_ERR_INVALID
     assert lib.nbody_multi_create_rank(ctypes.byref(m), ctypes.byref(cfg), 0, 0, 2, None) == _lib.NBODY_ERR_INVALID
     assert lib.nbody_multi_step(None, 0.1, 0.1) == _lib.NBODY_ERR_INVALID and lib.nbody_multi_destroy(None) == 0
+    assert lib.nbody_multi_reorder(None) == _lib.NBODY_ERR_INVALID and lib.nbody_multi_order(None, None) == _lib.NBODY_ERR_INVALID
+    assert lib.nbody_multi_set_reorder_period(None, 5) == _lib.NBODY_ERR_INVALID
 
 
 def _rank_without_gpu(rank, world, port, out_dir):
