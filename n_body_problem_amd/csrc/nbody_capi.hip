@@ -76,6 +76,7 @@ struct nbody_ctx {
     } graph_key;
     int graph_replay = -1;  // -1: automatic (systems of at most kGraphAutoBodies bodies), 0: off, 1: on
     hipStream_t aux_stream = nullptr;  // pair-once mode: the diagonal-tile launch runs here, beside the tile launch
+    hipStream_t tile_stream2 = nullptr;  // NBODY_SYM_TILE_STREAMS=2 (experiment): odd summation parts' tiles, lowest priority
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_graph_in = nullptr, ev_graph_out = nullptr;
     float4 *partials = nullptr;    // [n_splits][row_count]  (the reference's gravity_sum_array, kernel.cu:1148);
                                    // pair-once mode: [n_splits / 2 + 1][row_count].  Allocated at the first force call.
@@ -403,6 +404,7 @@ int nbody_destroy(nbody_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_graph_in) (void)hipEventDestroy(c->ev_graph_in);
     if (c->ev_graph_out) (void)hipEventDestroy(c->ev_graph_out);
+    if (c->tile_stream2) (void)hipStreamDestroy(c->tile_stream2);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1069,18 +1071,34 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         for (int p = 0; p < std::min(K, 2); ++p)
             if (int rc = diag_launch(p))
                 return rc;
+        // Experiment (NBODY_SYM_TILE_STREAMS=2): the odd parts' tile launches on a second stream of the lowest priority, not
+        // ordered behind the even parts': their first workgroups fill the tail of the launch before them.
+        static const bool two_tile_streams = getenv("NBODY_SYM_TILE_STREAMS") && atoi(getenv("NBODY_SYM_TILE_STREAMS")) == 2;
+        if (two_tile_streams && K > 1 && !c->tile_stream2) {
+            int least = 0, greatest = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->tile_stream2, hipStreamNonBlocking, least));
+        }
         for (int p = 0; p < K; ++p) {
             const nbody_ctx::SymPart &part = plan.parts[(size_t)p];
+            hipStream_t ts = two_tile_streams && (p & 1) ? c->tile_stream2 : c->stream;
+            if (ts != c->stream)
+                HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_fork, 0));  // the positions and the split masses are in place
             if (K > 2 && p >= 2)
-                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_red[(size_t)p - 2], 0));
+                HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_red[(size_t)p - 2], 0));
             part_args(part);
             {
-                TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);  // the dominant kernel alone
-                HIP_TRY(c, launch_forces_symmetric(sa, c->stream));
+                TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches, ts, true);  // the dominant kernel alone
+                HIP_TRY(c, launch_forces_symmetric(sa, ts));
             }
-            if (p == K - 1)
+            if (p == K - 1) {
+                if (ts != c->stream) {  // the last part's sums are formed on the context's stream
+                    HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], ts));
+                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_tiles[(size_t)p], 0));
+                }
                 break;
-            HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], c->stream));
+            }
+            HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], ts));
             HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_tiles[(size_t)p], 0));
             {
                 TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches, c->aux_stream, true);  // overlapped, like the diagonal
