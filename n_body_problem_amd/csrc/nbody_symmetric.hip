@@ -566,11 +566,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 
     // equal-mass tiles, eight rows per lane (S8_GROUP_LOOP): a wave owns 512 rows of a pass
     auto passes8 = [&]() {
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Which of the 64 bodies of a row block / column group a lane holds: 4 (lane mod 16) + lane / 16, so that the four
+        // lanes one ALU lane serves in consecutive cycles (l, l + 16, l + 32, l + 48) hold four CONSECUTIVE bodies -- with the
+        // bodies stored along a space-filling curve the operands of consecutive cycles then differ in few bits (power, hence
+        // clock).  Any assignment is correct; this one is part of the summation order.
+        const int sl = 4 * (lane & 15) + (lane >> 4);
         for (int pass0 = 0; pass0 < L; pass0 += kSymThreads * 8) {
             float4 p[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int r = pass0 + (wave * 8 + k) * 64 + lane;
+                const int r = pass0 + (wave * 8 + k) * 64 + sl;
                 p[k] = zero4;
                 if (r < L && rowbase + r < row_hi)
                     p[k] = a.pos[rowbase + r];
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 
             nb_f16 ra0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
             float4 cnext = zero4;  // the next group's column bodies, loaded a group ahead
             {
-                const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + lane;
+                const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + sl;
                 if (gc < a.n_total)
                     cnext = a.pos[gc];
             }
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 
                 st[128 + lane] = st[192 + lane] = cnext.y;
                 st[256 + lane] = st[320 + lane] = cnext.z;
                 if (g + 1 < G) {
-                    const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + lane;
+                    const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + sl;
                     cnext = zero4;
                     if (gc < a.n_total)
                         cnext = a.pos[gc];
@@ -608,7 +613,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 
                                "{v[8:9]}"(epsv), "{v10}"(next_lane)
                              : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
                                "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory");
-                const int ca = cg * 64 + ((lane + 32) & 63), cb = cg * 64 + lane;  // as in the four-row loop
+                // slot (lane + 32) mod 64 and slot lane of the stage: the bodies 4 (slot mod 16) + slot / 16 of the group
+                const int ca = cg * 64 + 4 * (lane & 15) + (((lane >> 4) + 2) & 3), cb = cg * 64 + sl;
                 lds.sx[ca] -= cx.x;
                 lds.sy[ca] -= cy.x;
                 lds.sz[ca] -= cz.x;
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int r = pass0 + (wave * 8 + k) * 64 + lane;
+                const int r = pass0 + (wave * 8 + k) * 64 + sl;
                 if (r < L && rowbase + r < row_hi)
                     out[rowbase + r - a.row_lo] = make_float3((sum[6 * k] + sum[6 * k + 1]) * row_scale,
                                                               (sum[6 * k + 2] + sum[6 * k + 3]) * row_scale,
