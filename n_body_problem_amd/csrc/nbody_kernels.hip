@@ -396,7 +396,10 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
     const int j0 = split * a.split_len;
     const int j1 = min(j0 + a.split_len, a.n_total);
     const int ntiles = (j1 - j0 + kTile - 1) / kTile;
-    const int row_base = blockIdx.x * (kTile * 4) + tid;
+    // Which row of its wave's 64 a lane takes: 4 (lane mod 16) + lane / 16, so that the four lanes one ALU lane serves in
+    // consecutive cycles hold four consecutive bodies (bodies along a space-filling curve: fewer operand bits toggle, see
+    // nbody_symmetric.hip).  A row's sum does not depend on the lane that forms it: not a bit changes.
+    const int row_base = blockIdx.x * (kTile * 4) + (tid & ~63) + 4 * (tid & 15) + ((tid >> 4) & 3);
     const float split_mass = GUARD ? __builtin_nanf("") : a.split_mass[split];  // see force_kernel
     const bool uniform = split_mass == split_mass;
 
