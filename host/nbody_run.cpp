@@ -63,7 +63,7 @@ int main(int argc, char **argv)
         else if (a == "--ring") ring = true;
         else if (a == "--peer-copy") peer_copy = true;
         else if (a == "--morton") morton = true;
-        else if (a == "--reorder-every") reorder_every = std::atoll(next().c_str());  // with --morton --devices: refresh the layout
+        else if (a == "--reorder-every") reorder_every = std::atoll(next().c_str());  // with --morton: refresh the layout
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-') {
             dataset = std::atoi(a.c_str());  // kernel.cu:1069-1086: argv[1] = dataset id, 0..5
@@ -178,7 +178,34 @@ int main(int argc, char **argv)
             std::printf("step %lld  E = %.9e (K %.6e U %.6e)\n", (long long)step0, e0.total, e0.kinetic, e0.potential);
         }
         const auto t0 = std::chrono::steady_clock::now();
+        auto upload = [&]() {  // b in the device's order -> the context (and the eps column as softening lengths)
+            sys.setParticlesPosition(b.pos.data());
+            sys.setParticlesVelocity(b.vel.data());
+            if (particle_eps) {
+                std::vector<float> eps((size_t)b.n());
+                for (std::int64_t i = 0; i < b.n(); ++i) eps[(size_t)i] = b.vel[4 * (size_t)i + 3];
+                sys.setParticleSoftening(eps.data());
+            }
+        };
         for (std::int64_t s = 1; s <= steps; ++s) {
+            if (!order.empty() && reorder_every > 0 && s > 1 && (s - 1) % reorder_every == 0) {
+                // a new curve through the current positions (the schedule of nbody_multi_set_reorder_period): the state in the
+                // file's order, sorted again, back to the device
+                sys.download(b.pos.data(), b.vel.data());
+                nbody_io::Bodies given = b;
+                for (std::int64_t k = 0; k < b.n(); ++k)
+                    for (int c = 0; c < 4; ++c) {
+                        given.pos[4 * (size_t)order[(size_t)k] + c] = b.pos[4 * (size_t)k + c];
+                        given.vel[4 * (size_t)order[(size_t)k] + c] = b.vel[4 * (size_t)k + c];
+                    }
+                if (nbody_morton_order(given.pos.data(), b.n(), order.data()) != NBODY_OK) throw std::runtime_error("nbody_morton_order failed");
+                for (std::int64_t k = 0; k < b.n(); ++k)
+                    for (int c = 0; c < 4; ++c) {
+                        b.pos[4 * (size_t)k + c] = given.pos[4 * (size_t)order[(size_t)k] + c];
+                        b.vel[4 * (size_t)k + c] = given.vel[4 * (size_t)order[(size_t)k] + c];
+                    }
+                upload();
+            }
             sys.step(dt, softening);                    // the bracket kernel.cu:1225-1242
             const std::int64_t gs = step0 + s;
             if (energy_every > 0 && (s % energy_every == 0 || s == steps)) {

@@ -108,6 +108,18 @@ def test_cli_morton_flag_matches_the_python_mirror_and_keeps_the_files_order(tmp
             tmp_path / "one.nbs")
     p, v, _, _ = ds.load_snapshot(str(tmp_path / "one.nbs"))
     assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
+    # the layout refreshed every 4 steps: the schedule of set_reorder_period / nbody_multi_set_reorder_period
+    with nb.NBodySystem(6000, body_order="morton") as s:
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.set_particle_softening(vel[:, 3])
+        s.set_reorder_period(4)
+        s.step_n(10, 5e-3, 1e-3)
+        want10_p, want10_v = s.download()
+    run_cli("--resume", start, "--steps", 10, "--dt", 5e-3, "--softening", 1e-3, "--particle-softening", "--morton",
+            "--reorder-every", 4, "--final", tmp_path / "ten.nbs")
+    p10, v10, _, _ = ds.load_snapshot(str(tmp_path / "ten.nbs"))
+    assert np.array_equal(p10, want10_p) and np.array_equal(v10, want10_v)
     run_cli("--resume", start, "--steps", 3, "--dt", 1e-3, "--softening", 1e-3, "--particle-softening", "--morton",
             "--devices", "0,0", "--peer-copy", "--final", tmp_path / "two.nbs")
     p2, v2, _, _ = ds.load_snapshot(str(tmp_path / "two.nbs"))
