@@ -249,34 +249,55 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
 #define S8_RSQ "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"
 #define S8_TA "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]"
 #define S8_TB "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]"
+// A batch = two rows (temps A and B) x two columns, its instructions interleaved A, B: consecutive instructions then work
+// on the same kind of operand (the column pair's x against row A's x, then row B's x: few bits toggle) and no result is used
+// by the next instruction.  Each sum still receives its terms in the order A, B.  Q of row B in v[58:59].
+#ifdef NB_S8_SEQUENTIAL /* the batch as two rows one after the other (A/B measurement) */
+#define S8_PRE2(RXYA, RXYB, RZZ) S8_PRE(RXYA, RZZ, S8_ZLO, S8_TA) S8_PRE(RXYB, RZZ, S8_ZHI, S8_TB)
+#define S8_POST2(AXA, AYA, AZA, AXB, AYB, AZB) S8_POST(AXA, AYA, AZA, S8_TA) S8_POST(AXB, AYB, AZB, S8_TB)
+#else
+#define S8_PRE2(RXYA, RXYB, RZZ)                                                                                 \
+    "v_pk_add_f32 v[30:31], v[2:3], " RXYA " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                   \
+    "v_pk_add_f32 v[42:43], v[2:3], " RXYB " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                   \
+    "v_pk_add_f32 v[34:35], v[6:7], " RXYA " op_sel:[0,1] op_sel_hi:[1,1]" S2_NEG                                   \
+    "v_pk_add_f32 v[46:47], v[6:7], " RXYB " op_sel:[0,1] op_sel_hi:[1,1]" S2_NEG                                   \
+    "v_pk_add_f32 v[38:39], v[4:5], " RZZ S8_ZLO S2_NEG                                                             \
+    "v_pk_add_f32 v[50:51], v[4:5], " RZZ S8_ZHI S2_NEG                                                             \
+    "v_pk_fma_f32 v[28:29], v[30:31], v[30:31], v[8:9] op_sel_hi:[1,1,0]\n\t"                                       \
+    "v_pk_fma_f32 v[32:33], v[42:43], v[42:43], v[8:9] op_sel_hi:[1,1,0]\n\t"                                       \
+    "v_pk_fma_f32 v[28:29], v[34:35], v[34:35], v[28:29]\n\tv_pk_fma_f32 v[32:33], v[46:47], v[46:47], v[32:33]\n\t" \
+    "v_pk_fma_f32 v[28:29], v[38:39], v[38:39], v[28:29]\n\tv_pk_fma_f32 v[32:33], v[50:51], v[50:51], v[32:33]\n\t"
+#define S8_POST2(AXA, AYA, AZA, AXB, AYB, AZB)                                                                   \
+    "v_pk_mul_f32 v[54:55], v[28:29], v[28:29]\n\tv_pk_mul_f32 v[58:59], v[32:33], v[32:33]\n\t"                     \
+    "v_pk_mul_f32 v[28:29], v[28:29], v[54:55]\n\tv_pk_mul_f32 v[32:33], v[32:33], v[58:59]\n\t"                     \
+    "v_pk_fma_f32 " AXA ", v[30:31], v[28:29], " AXA "\n\tv_pk_fma_f32 " AXB ", v[42:43], v[32:33], " AXB "\n\t"     \
+    "v_pk_fma_f32 " AYA ", v[34:35], v[28:29], " AYA "\n\tv_pk_fma_f32 " AYB ", v[46:47], v[32:33], " AYB "\n\t"     \
+    "v_pk_fma_f32 " AZA ", v[38:39], v[28:29], " AZA "\n\tv_pk_fma_f32 " AZB ", v[50:51], v[32:33], " AZB "\n\t"     \
+    "v_pk_fma_f32 v[36:37], v[30:31], v[28:29], v[36:37]\n\tv_pk_fma_f32 v[40:41], v[34:35], v[28:29], v[40:41]\n\t" \
+    "v_pk_fma_f32 v[44:45], v[38:39], v[28:29], v[44:45]\n\t"                                                       \
+    "v_pk_fma_f32 v[36:37], v[42:43], v[32:33], v[36:37]\n\tv_pk_fma_f32 v[40:41], v[46:47], v[32:33], v[40:41]\n\t" \
+    "v_pk_fma_f32 v[44:45], v[50:51], v[32:33], v[44:45]\n\t"
+#endif
 #define S8_STEP(NEXT)                                                                                            \
     "s_waitcnt lgkmcnt(6)\n\t" /* the column pair has arrived; the six permutes behind it may be in flight */    \
-    S8_PRE("v[12:13]", "v[14:15]", S8_ZLO, S8_TA)                                                                \
-    S8_PRE("v[16:17]", "v[14:15]", S8_ZHI, S8_TB)                                                                \
+    S8_PRE2("v[12:13]", "v[16:17]", "v[14:15]")                                                                  \
     S8_RSQ NB_SYM_GAP                                                                                            \
     "s_waitcnt lgkmcnt(0)\n\t" /* the column sums have arrived from the next lane */                             \
     NB_SYM_PRIO_POST                                                                                             \
-    S8_POST("v[64:65]", "v[66:67]", "v[68:69]", S8_TA)                                                           \
-    S8_POST("v[70:71]", "v[72:73]", "v[74:75]", S8_TB)                                                           \
+    S8_POST2("v[64:65]", "v[66:67]", "v[68:69]", "v[70:71]", "v[72:73]", "v[74:75]")                             \
     NB_SYM_PRIO_PRE                                                                                              \
-    S8_PRE("v[20:21]", "v[18:19]", S8_ZLO, S8_TA)                                                                \
-    S8_PRE("v[24:25]", "v[18:19]", S8_ZHI, S8_TB)                                                                \
+    S8_PRE2("v[20:21]", "v[24:25]", "v[18:19]")                                                                  \
     S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
-    S8_POST("v[76:77]", "v[78:79]", "v[80:81]", S8_TA)                                                           \
-    S8_POST("v[82:83]", "v[84:85]", "v[86:87]", S8_TB)                                                           \
+    S8_POST2("v[76:77]", "v[78:79]", "v[80:81]", "v[82:83]", "v[84:85]", "v[86:87]")                             \
     NB_SYM_PRIO_PRE                                                                                              \
-    S8_PRE("v[48:49]", "v[22:23]", S8_ZLO, S8_TA)                                                                \
-    S8_PRE("v[52:53]", "v[22:23]", S8_ZHI, S8_TB)                                                                \
+    S8_PRE2("v[48:49]", "v[52:53]", "v[22:23]")                                                                  \
     S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
-    S8_POST("v[88:89]", "v[90:91]", "v[92:93]", S8_TA)                                                           \
-    S8_POST("v[94:95]", "v[96:97]", "v[98:99]", S8_TB)                                                           \
+    S8_POST2("v[88:89]", "v[90:91]", "v[92:93]", "v[94:95]", "v[96:97]", "v[98:99]")                             \
     NB_SYM_PRIO_PRE                                                                                              \
-    S8_PRE("v[56:57]", "v[26:27]", S8_ZLO, S8_TA)                                                                \
-    S8_PRE("v[60:61]", "v[26:27]", S8_ZHI, S8_TB)                                                                \
+    S8_PRE2("v[56:57]", "v[60:61]", "v[26:27]")                                                                  \
     NEXT /* the next step's column pair: the current one has been consumed by the eight PRE blocks */            \
     S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
-    S8_POST("v[100:101]", "v[102:103]", "v[104:105]", S8_TA)                                                     \
-    S8_POST("v[106:107]", "v[108:109]", "v[110:111]", S8_TB)                                                     \
+    S8_POST2("v[100:101]", "v[102:103]", "v[104:105]", "v[106:107]", "v[108:109]", "v[110:111]")                 \
     NB_SYM_PRIO_PRE                                                                                              \
     S8_ROTATE
 #define S8_GROUP_LOOP                                                                                            \
@@ -612,7 +633,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 
                              : "{v[12:27]}"(rows), "{v[48:49]}"(xy4), "{v[52:53]}"(xy5), "{v[56:57]}"(xy6), "{v[60:61]}"(xy7),
                                "{v[8:9]}"(epsv), "{v10}"(next_lane)
                              : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
-                               "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory");
+                               "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v58", "v59", "scc", "memory");
                 // slot (lane + 32) mod 64 and slot lane of the stage: the bodies 4 (slot mod 16) + slot / 16 of the group
                 const int ca = cg * 64 + 4 * (lane & 15) + (((lane >> 4) + 2) & 3), cb = cg * 64 + sl;
                 lds.sx[ca] -= cx.x;
