@@ -174,10 +174,21 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
     return len;
 }
 
+static int morton_order_impl(const float *xyzm, int64_t n, int64_t *perm);
+
 int nbody_morton_order(const float *xyzm, int64_t n, int64_t *perm)
 {
     if (n < 0 || (n > 0 && (!xyzm || !perm)))
         return NBODY_ERR_INVALID;
+    try {
+        return morton_order_impl(xyzm, n, perm);
+    } catch (...) {  // host allocation
+        return NBODY_ERR_ALLOC;
+    }
+}
+
+static int morton_order_impl(const float *xyzm, int64_t n, int64_t *perm)
+{
     // the bounding cube of the finite positions
     float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
     bool any = false;
@@ -232,11 +243,18 @@ int nbody_morton_order(const float *xyzm, int64_t n, int64_t *perm)
     // Host threads over contiguous chunks (a refresh of the layout costs a run as much as this function takes).
     const int threads = (int)std::max<int64_t>(1, std::min<int64_t>({8, (int64_t)std::thread::hardware_concurrency(), n / 65536}));
     auto chunk = [&](int t) { return std::make_pair(n * t / threads, n * (t + 1) / threads); };
-    auto in_parallel = [&](auto &&body) {
+    auto in_parallel = [&](auto &&body) {  // chunks that get no thread run on this one: nothing is thrown across the C ABI
         std::vector<std::thread> pool;
-        for (int t = 1; t < threads; ++t)
-            pool.emplace_back(body, t);
+        int started = 1;
+        try {
+            pool.reserve((size_t)threads);
+            for (; started < threads; ++started)
+                pool.emplace_back(body, started);
+        } catch (...) {
+        }
         body(0);
+        for (int t = started; t < threads; ++t)
+            body(t);
         for (auto &th : pool)
             th.join();
     };
