@@ -203,15 +203,35 @@ def forwarded_args(argv):
     return ["--bodies" if a == "--n" else "--bodies=" + a[4:] if a.startswith("--n=") else a for a in argv]
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT initialising a HIP runtime here (on ROCm builds without amdsmi
+    torch.cuda.device_count() falls back to hipGetDeviceCount, which does): the visibility variables, else the kfd topology
+    (a node with SIMDs is a GPU).  None when neither says anything -- the ranks check for themselves."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    count = 0
+    for f in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+            count += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            return None
+    return count
+
+
 def launch_ranks(args):
     """--gpus N without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) from a parent that
-    never touches a GPU, relay their output and return the exit code -- non-zero when fewer than N devices are visible,
-    a rank fails, or rank 0's line does not report n_gpus = N."""
+    never touches a GPU (it does not even count them through the HIP runtime), relay their output and return the exit
+    code -- non-zero when fewer than N devices are visible, a rank fails, or rank 0's line does not report n_gpus = N."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
-    if not args.single_device and have < args.gpus:
+    have = visible_gpu_count()
+    if not args.single_device and have is not None and have < args.gpus:
         log(f"bench.py: --gpus {args.gpus} but {have} device(s) visible")
         return 2
     with socket.socket() as sock:
@@ -222,11 +242,15 @@ def launch_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *forwarded]
     log("bench.py: launching", " ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-    line = None
+    line, errors = None, []
     for out in res.stdout.splitlines():
         if out.startswith("{"):
             try:
-                if "metric" in json.loads(out):
+                d = json.loads(out)
+                if "metric" in d and "error" in d:
+                    errors.append(out)
+                    continue
+                if "metric" in d:
                     line = out
                     continue
             except ValueError:
@@ -234,12 +258,64 @@ def launch_ranks(args):
         log(out)
     if res.returncode != 0:
         log(f"bench.py: the ranks exited with code {res.returncode}")
+        if errors:
+            print(errors[0], flush=True)              # the evidence a failed exchange leaves (one line, like a result)
         return res.returncode
     if line is None or json.loads(line).get("n_gpus") != args.gpus:
         log("bench.py: rank 0 printed no result line for the requested rank count")
         return 3
     print(line, flush=True)
     return 0
+
+
+def error_line(args, rank, world, what):
+    """A failed run leaves ONE JSON line with "error" on stdout (and the caller exits non-zero): a stalled first contact of
+    the exchange must leave evidence, not a kill at the driver's limit."""
+    return json.dumps({"metric": "body-body interactions/sec", "value": None, "unit": "interactions/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "error": what, "rank": rank,
+                       "config": {"n_bodies": args.n, "transport": args.transport, "exchange": args.exchange,
+                                  "exchange_timeout_s": args.exchange_timeout}})
+
+
+def per_step(tm, steps):
+    """One rank's share of a step from the library's event totals (milliseconds per step; sums of durations, not wall)."""
+    k = max(1, steps)
+    out = {"force_ms": tm["force_ms"] / k, "force_launches_per_step": tm["force_launches"] / k,
+           "update_ms": tm["update_ms"] / k, "aux_ms": tm.get("aux_ms", 0.0) / k}
+    for key in ("host_enqueue_ms", "pos_exchange_comm_ms", "pos_exchange_wait_ms", "column_sum_exchange_ms", "reorder_ms"):
+        if key in tm:
+            out[key] = tm[key] / k
+    return out
+
+
+def peer_copy_leg(args, timeout_s=240.0):
+    """The same job with the ranks' exchange done by peer copies from ONE process (nbody_multi_create over N devices,
+    hipMemcpyPeerAsync instead of RCCL): a labelled secondary measurement, run in a child process after the ranks are
+    done, so that a scaling curve exists even if the RCCL leg misbehaves -- and so that nothing it does can lose the main
+    line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID") and not k.startswith("TORCHELASTIC_")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--bodies", str(args.n), "--dt", str(args.dt), "--softening", str(args.softening), "--exchange",
+           args.exchange, "--force-mode", args.force_mode, "--body-order", args.body_order, "--transport", "peer_copy",
+           "--no-cpu-baseline", "--no-extra-legs", "--no-sanity"] + (["--single-device"] if args.single_device else [])
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {timeout_s:.0f} s"}
+    for out in res.stdout.splitlines():
+        if out.startswith("{"):
+            try:
+                d = json.loads(out)
+            except ValueError:
+                continue
+            keep = ("value", "ms_per_step", "n_gpus", "error", "per_rank", "roofline", "force_only_interactions_per_s")
+            leg = {k: d[k] for k in keep if k in d}
+            leg["transport"] = "peer_copy: one process drives all ranks, hipMemcpyPeerAsync between the replicas (no RCCL)"
+            return leg
+    return {"error": f"exit code {res.returncode}: " + res.stderr[-400:]}
 
 
 def main():
@@ -251,11 +327,20 @@ def main():
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--softening", type=float, default=1e-3)
     ap.add_argument("--exchange", default=os.environ.get("NBODY_EXCHANGE", "allgather"), choices=["allgather", "ring"])
+    ap.add_argument("--transport", default=os.environ.get("NBODY_TRANSPORT", "rccl"), choices=["rccl", "peer_copy"],
+                    help="rccl (the product path: one process per GPU, RCCL over xGMI); peer_copy: ONE process drives all "
+                         "--gpus ranks and moves the rows with hipMemcpyPeerAsync (no launcher, no RCCL) -- a labelled "
+                         "secondary measurement; an rccl run with --gpus > 1 appends it as \"peer_copy_leg\"")
+    ap.add_argument("--exchange-timeout", type=float, default=60.0,
+                    help="seconds a rank waits for an exchange before it aborts the communicators and reports (library "
+                         "default: 600)")
     ap.add_argument("--rows-per-lane", type=int, default=0)
     ap.add_argument("--body-order", default=os.environ.get("NBODY_BODY_ORDER", "morton"), choices=["morton", "given"],
-                    help="how the library stores the bodies it is given: along a Morton curve (nbody_morton_order at upload, "
+                    help="how the library stores the bodies it is given: along a Morton curve (laid on the device at upload, "
                          "undone at download: neighbours in memory are neighbours in space, fewer operand bits toggle, the "
                          "power-limited clock rises) or in the generator's (random) order; the other one is reported as a leg")
+    ap.add_argument("--reorder-every", type=int, default=0,
+                    help="body-order morton: refresh the layout on the device every so many steps (0: never)")
     ap.add_argument("--force-mode", default=os.environ.get("NBODY_FORCE_MODE", "pair_once"),
                     choices=["pair_once", "one_sided", "symmetric"],
                     help="pair_once (= symmetric): each unordered pair once; one_sided: every ordered interaction")
@@ -263,7 +348,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sanity", action="store_true", help="skip the energy / replica checks around the timed region")
     ap.add_argument("--no-extra-legs", "--no-pair-once", dest="no_extra_legs", action="store_true",
-                    help="skip the extra legs (the other force mode, the reference's N = 20000)")
+                    help="skip the extra legs (the other force mode, the reference's N = 20000, the peer-copy leg)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the product path); gloo only to rehearse the multi-rank flow on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -271,11 +356,12 @@ def main():
     mode = "pair_once" if args.force_mode == "symmetric" else args.force_mode
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    one_process = args.transport == "peer_copy" or args.gpus == 1
+    if not one_process and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))           # before anything here touches a GPU
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = args.gpus if one_process else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if one_process else int(os.environ.get("RANK", "0"))
+    local_rank = 0 if one_process else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different job")
     if mode == "pair_once" and 8 % world:
@@ -295,7 +381,8 @@ def main():
     elif torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} devices")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    distributed = world > 1 and not one_process
+    if distributed:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -303,67 +390,98 @@ def main():
 
     n = args.n
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
-    if world == 1:
-        system = nb.NBodySystem(n, device=local_rank, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0,
-                                body_order=args.body_order)
-        system.set_force_mode(mode)
-        kernels = system
-    else:
-        # nccl backend: MultiGpuSystem, the exchange inside the library; gloo: the host-staged rehearsal harness
-        system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode,
-                                body_order=args.body_order if args.backend == "nccl" else "given")
-        kernels = system.kernels
-    library_exchange = isinstance(system, MultiGpuSystem)
-    rccl_ranks = system.info()["rccl_ranks"] if library_exchange else None
-    if library_exchange and rccl_ranks != world:
-        raise SystemExit(f"bench.py: the RCCL communicator has {rccl_ranks} ranks, expected {world}")
-    kernels.set_rows_per_lane(args.rows_per_lane)
-    system.setParticlesPosition(pos)
-    system.setParticlesVelocity(vel)
-    info = kernels.device_info()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    # outside the timed region: the energy before and after, and a check that every rank ends with the same positions
-    e_before = None if args.no_sanity else system.energy(args.softening)
-    kernels.timing(True)
-    for _ in range(args.warmup):
-        system.step(args.dt, args.softening, sync=False)
-    system.sync()
-    kernels.read_timing()  # reset the event totals
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        system.step(args.dt, args.softening, sync=False)
-    system.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tm = kernels.read_timing()
-    kernels.timing(False)
-    sanity = None
-    if not args.no_sanity:
-        e_after = system.energy(args.softening)
-        if library_exchange:
-            identical = system.replicas_identical()
+    try:
+        if world == 1:
+            system = nb.NBodySystem(n, device=local_rank, split_len=nb.pair_once_split_len(n) if mode == "pair_once" else 0,
+                                    body_order=args.body_order)
+            system.set_force_mode(mode)
+            kernels = system
+        elif one_process:
+            # every rank in this process, rows moved by peer copies: no launcher, no RCCL (the labelled secondary measurement)
+            devices = [0] * world if args.single_device else list(range(world))
+            system = MultiGpuSystem(n, devices=devices, force_mode=mode, exchange=args.exchange, transport="peer_copy",
+                                    body_order=args.body_order)
+            kernels = system.kernels
         else:
-            digest = system.positions.view(torch.int32).to(torch.int64).sum().reshape(1)
-            lo, hi = digest.clone(), digest.clone()
-            if world > 1:
-                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            identical = int(lo.item()) == int(hi.item())
-        sanity = {"energy_before": float(e_before[2]), "energy_after": float(e_after[2]),
-                  "dE_over_E0": float((e_after[2] - e_before[2]) / abs(e_before[2])),
-                  "steps_between": args.warmup + args.steps,
-                  "position_replicas_identical_on_all_ranks": bool(identical)}
+            # nccl backend: MultiGpuSystem, the exchange inside the library; gloo: the host-staged rehearsal harness
+            system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode,
+                                    body_order=args.body_order if args.backend == "nccl" else "given")
+            kernels = system.kernels
+        library_exchange = isinstance(system, MultiGpuSystem)
+        rccl_ranks = system.info()["rccl_ranks"] if library_exchange else None
+        if library_exchange and not one_process and rccl_ranks != world:
+            raise SystemExit(f"bench.py: the RCCL communicator has {rccl_ranks} ranks, expected {world}")
+        if library_exchange:
+            system.set_timeout(args.exchange_timeout)   # well inside any driver limit: a dead peer is reported, not waited for
+        if args.reorder_every and hasattr(system, "set_reorder_period"):
+            system.set_reorder_period(args.reorder_every)
+        kernels.set_rows_per_lane(args.rows_per_lane)
+        system.setParticlesPosition(pos)
+        system.setParticlesVelocity(vel)
+        info = kernels.device_info()
+
+        def barrier():
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+
+        def run_steps(k):
+            if args.reorder_every and not library_exchange:
+                system.step_n(k, args.dt, args.softening)       # the Python layer's schedule of refreshes
+                return
+            for _ in range(k):
+                system.step(args.dt, args.softening, sync=False)
+            system.sync()
+
+        def read_timing():
+            if library_exchange:                                 # kernels + exchanges, every local rank
+                return [system.read_timing(i) for i in range(system.local_ranks)]
+            return [kernels.read_timing()]
+
+        # outside the timed region: the energy before and after, and a check that every rank ends with the same positions
+        e_before = None if args.no_sanity else system.energy(args.softening)
+        (system if library_exchange else kernels).timing(True)
+        run_steps(args.warmup)
+        read_timing()  # reset the event totals
+
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        local_tm = read_timing()
+        tm = local_tm[0]
+        (system if library_exchange else kernels).timing(False)
+        per_rank = [dict(rank=rank + i, **per_step(t, args.steps)) for i, t in enumerate(local_tm)]
+        if distributed:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, per_rank)
+            per_rank = [x for part in gathered for x in part]
+        sanity = None
+        if not args.no_sanity:
+            e_after = system.energy(args.softening)
+            if library_exchange:
+                identical = system.replicas_identical()
+            else:
+                digest = system.positions.view(torch.int32).to(torch.int64).sum().reshape(1)
+                lo, hi = digest.clone(), digest.clone()
+                if distributed:
+                    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                identical = int(lo.item()) == int(hi.item())
+            sanity = {"energy_before": float(e_before[2]), "energy_after": float(e_after[2]),
+                      "dE_over_E0": float((e_after[2] - e_before[2]) / abs(e_before[2])),
+                      "steps_between": args.warmup + args.steps,
+                      "position_replicas_identical_on_all_ranks": bool(identical)}
+    except nb.NBodyError as e:
+        # the library gave up on an exchange (timeout, RCCL error) or refused the job: say so in one line and leave
+        print(error_line(args, rank, world, str(e)), flush=True)
+        log(f"bench.py: rank {rank}: {e}")
+        os._exit(1)                                     # no barrier, no destructor may wait for a peer that is gone
 
     out = None
     if rank == 0:
@@ -387,20 +505,27 @@ def main():
                                    f"softening={args.softening}, dt={args.dt}",
                        "n_bodies": n, "parallelism": f"rows sharded x{world}" if world > 1 else "1 GPU",
                        "exchange": args.exchange if world > 1 else None,
-                       "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+                       "backend": ("peer_copy (one process, hipMemcpyPeerAsync; secondary measurement)" if one_process else
+                                   "rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
                        "exchange_owner": ("library (nbody_multi_*, csrc/nbody_multi.hip)" if library_exchange else
                                           "torch.distributed rehearsal harness") if world > 1 else None,
+                       "exchange_timeout_s": args.exchange_timeout if library_exchange else None,
                        "rccl_ranks": rccl_ranks,
                        "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3],
                        "force_mode": mode,
-                       # the layout the library keeps the generator's bodies in (upload option, undone at download; the
-                       # other order is the `other_body_order` leg of the N = 1 run)
-                       "body_order": getattr(system, "body_order", "given")},
+                       # the layout the library keeps the generator's bodies in (laid on the device at upload, undone at
+                       # download; the other order is the `other_body_order` leg of the N = 1 run)
+                       "body_order": getattr(system, "body_order", "given"),
+                       "reorder_every": args.reorder_every or None},
             "roofline": roofline(mode, n, int(getattr(system, "split_len", 0)), rows_here, args.steps, tm,
                                  equal_mass=bool(np.all(pos[:, 3] == pos[0, 3]))),
             "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
             "update_ms_per_step": tm["update_ms"] / args.steps,
             "overlapped_aux_ms_per_step": tm.get("aux_ms", 0.0) / args.steps,   # diagonal tiles + early summation, beside the tiles
+            # where every rank's step goes (library event totals, ms per step): its kernels, the position exchange on the
+            # communication stream and as the waiting force launch saw it, the pair-once column-sum exchange (not hidden,
+            # by design), and the host time spent enqueuing a step
+            "per_rank": per_rank if world > 1 else None,
             # pair-once mode on one context: the tile launches per pass and what the two partial-sum arrays hold (two of the
             # parts; n^2 / split_len 12-byte entries would be the whole pass)
             "summation_parts": tm["force_launches"] // max(1, args.steps) if mode == "pair_once" and world == 1 else None,
@@ -426,10 +551,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, args.softening, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     system.close()
+    if out is not None and distributed and args.backend == "nccl" and not args.no_extra_legs:
+        out["peer_copy_leg"] = peer_copy_leg(args)      # a child process, after this rank has let go of its GPU objects
     if out is not None:
         print(json.dumps(out), flush=True)
 

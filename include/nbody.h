@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 3
+#define NBODY_ABI_VERSION 4
 #define NBODY_MIN_SOFTENING 1.0e-9f
 
 typedef struct nbody_ctx nbody_ctx;
@@ -64,6 +64,11 @@ const char *nbody_status_string(int status);
 int nbody_create(nbody_ctx **out, int device, int64_t n_total);
 int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row_lo, int64_t row_count,
                        int64_t split_len);
+/* nbody_create_auto: nbody_create with the force mode that is faster at this body count already selected, and the split
+ * length that mode wants (what nbody_set_force_mode(ctx, NBODY_FORCE_AUTO) does to an existing context): the pair-once
+ * kernels from NBODY_PAIR_ONCE_MIN_BODIES bodies on, the one-sided ones below.  The one call a caller of the reference's
+ * bracket (kernel.cu:1225-1242) needs to land on the fast kernels at every N. */
+int nbody_create_auto(nbody_ctx **out, int device, int64_t n_total);
 int nbody_destroy(nbody_ctx *ctx);
 const char *nbody_last_error(const nbody_ctx *ctx); /* ctx == NULL: last error of a failed create */
 int64_t nbody_default_split_len(int64_t n_total);
@@ -85,6 +90,37 @@ int64_t nbody_n_total(const nbody_ctx *ctx);
 #define NBODY_ORDER_MAX_SPECIES 16
 enum { NBODY_ORDER_GIVEN = 0, NBODY_ORDER_MORTON = 1 };
 int nbody_morton_order(const float *host_xyzm, int64_t n, int64_t *perm);
+
+/* ---- the same order computed ON THE DEVICE (csrc/nbody_order.hip): a layout refresh without a host copy of the state ----
+ * The layout decays as the bodies move (N = 2^20, dt = 1e-3: half of the gain is gone after ~300 steps); through the host a
+ * refresh costs 0.13-0.3 s at N = 2^20, here well under a millisecond of device time (bounding cube and mass species by
+ * atomics, keys in double exactly as the host computes them, a stable 64-bit radix sort, gathers) -- the SAME permutation
+ * as nbody_morton_order, bit for bit, so every rank of a multi-GPU run gets it from its own replica.  All calls are
+ * asynchronous on the context's stream.
+ * nbody_reorder: a context that owns every row: the first n bodies (n <= n_total; a zero-mass padding tail stays where it
+ *   is) of d_positions_xyzm, d_velocities_xyzw and, when not NULL, d_eps (n floats, e.g. the array given to
+ *   nbody_set_particle_softening) are permuted in place into nbody_morton_order of the CURRENT positions; the context's own
+ *   softening copy (nbody_upload_particle_softening) follows; d_order (n int64 on the device, or NULL) is composed:
+ *   d_order[k] <- d_order[perm[k]], so that an array started with nbody_order_identity keeps saying which of the caller's
+ *   bodies sits in slot k -- and bodies with equal keys are placed in the order of THOSE indices, so the layout is
+ *   nbody_morton_order of the bodies in the caller's order, a pure function of the body set, however often it has been
+ *   refreshed.  Cached accelerations (kick-drift-kick) are forgotten.
+ * nbody_morton_order_device: only the permutation, n int64 on the device.
+ * The pieces, for a sharded host (nbody_multi_reorder is built from them): nbody_order_compute keeps the permutation of
+ *   the first n bodies in the context (the identity beyond n; d_order as above, or NULL); nbody_order_gather applies it,
+ *   d_dst[j] = d_src[perm[first + j]] for j < count, rows of 1, 2 (one int64) or 4 floats, d_src indexed by body -- in
+ *   place (d_dst == d_src) only from first = 0; nbody_order_read widens it to int64; nbody_order_permute_softening
+ *   applies it to the context's own softening copy, if it has one in use. */
+int nbody_reorder(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, float *d_eps, int64_t *d_order, int64_t n);
+int nbody_morton_order_device(nbody_ctx *ctx, const float *d_xyzm, int64_t n, int64_t *d_perm);
+int nbody_order_compute(nbody_ctx *ctx, const float *d_xyzm, int64_t n, const int64_t *d_order);
+int nbody_order_gather(nbody_ctx *ctx, void *d_dst, const void *d_src, int64_t first, int64_t count, int floats_per_row);
+int nbody_order_read(nbody_ctx *ctx, int64_t *d_perm);
+int nbody_order_identity(nbody_ctx *ctx, int64_t *d_order, int64_t n);
+/* The context's permutation from an index array on the device: perm[k] = d_order[k], or, inverse != 0, perm[d_order[k]] = k
+ * (d_order a permutation of 0..n-1): gathering with the inverse of an order array puts the bodies back in the caller's order. */
+int nbody_order_set(nbody_ctx *ctx, const int64_t *d_order, int64_t n, int inverse);
+int nbody_order_permute_softening(nbody_ctx *ctx);
 
 /* ---- context-owned buffers: setParticlesPosition / setParticlesVelocity, kernel.cu:163-188 ----
  * Host arrays of n_total float4 (positions) and row_count float4 (velocities of this context's rows).
@@ -194,7 +230,14 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
  *     [all-gather the contexts' slices of the colparts buffer -- the caller's job, e.g. RCCL]
  *     nbody_update / nbody_kdk_*                (adds row-side and column-side sums in the fixed order)
  * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
-enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1 };
+/* NBODY_FORCE_AUTO (nbody_set_force_mode only; a context that owns every row, nothing pending): the pair-once mode from
+ * NBODY_PAIR_ONCE_MIN_BODIES bodies on -- where it delivers more interactions per second (N = 65 536: 0.77 against 0.95 ms
+ * per step; N = 2^20: 150 against 229 ms) -- the one-sided mode below, where the pair-once grid is too coarse to fill the
+ * chip (N = 20 225: 0.18 against 0.15 ms), and the context's split length is changed to the one that mode wants
+ * (nbody_pair_once_split_len / nbody_default_split_len).  nbody_force_mode reads the mode in use. */
+#define NBODY_PAIR_ONCE_MIN_BODIES 65536
+enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1, NBODY_FORCE_AUTO = 2 };
+int nbody_force_mode(const nbody_ctx *ctx);
 /* The split length to create a pair-once context with.  A function of n_total ONLY (split boundaries define the
  * summation order, so they must not depend on the sharding): 1024 from 204 800 bodies up -- the kernel's rows per
  * pass, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles below that (small systems
@@ -266,7 +309,8 @@ int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);
  * one RCCL communicator; nbody_multi_step is the whole step (csrc/nbody_multi.hip):
  *     own-chunk force launch  ||  all-gather of the previous step's updated rows (in place, RCCL over xGMI)
  *     complement force launch behind the all-gather, on the second stream
- *     [pair-once mode: column-side sums, one more all-gather]      update; the next all-gather is issued behind it.
+ *     [pair-once mode: column-side sums of the rank's groups, then every rank hands every other rank the segments of its
+ *      rows -- ncclSend / ncclRecv to each peer inside one group call]   update; the next all-gather is issued behind it.
  * The body count need not divide: the system is padded with zero-mass bodies at the origin (the reference's own padding
  * device, kernel.cu:265-277) to n_padded = P x rows_per_rank, rows_per_rank whole splits (whole split groups in the
  * pair-once mode, which therefore shards over 1, 2, 4 or 8 ranks).  The state is bit-identical to ONE context on the
@@ -288,7 +332,8 @@ enum { NBODY_TRANSPORT_RCCL = 0,
 typedef struct nbody_multi_config {
     int64_t n_bodies;  /* real bodies */
     int64_t split_len; /* 0 = nbody_default_split_len / nbody_pair_once_split_len of n_bodies */
-    int force_mode;    /* NBODY_FORCE_ONE_SIDED | NBODY_FORCE_SYMMETRIC */
+    int force_mode;    /* NBODY_FORCE_ONE_SIDED | NBODY_FORCE_SYMMETRIC | NBODY_FORCE_AUTO (pair-once from
+                          NBODY_PAIR_ONCE_MIN_BODIES bodies on when the rank count divides NBODY_SYM_GROUPS) */
     int integrator;    /* NBODY_INTEGRATOR_KICK_DRIFT | NBODY_INTEGRATOR_KDK */
     int exchange;      /* NBODY_EXCHANGE_* */
     int transport;     /* NBODY_TRANSPORT_* */
@@ -315,6 +360,11 @@ int nbody_multi_set_timeout(nbody_multi *m, double seconds);
  * rank's replica and velocity rows are filled.  download: all n_bodies rows on every process (either pointer may be
  * NULL).  set_particle_softening: n_bodies host floats or NULL. */
 int nbody_multi_set_state(nbody_multi *m, const float *host_xyzm, const float *host_xyzw);
+/* The reference's two setters are independent copies (kernel.cu:163-188); so are these: new positions keep every body's
+ * velocity and softening length (with NBODY_ORDER_MORTON the new curve is laid through the new positions and the velocities
+ * follow their bodies), new velocities leave the positions and the layout alone. */
+int nbody_multi_set_positions(nbody_multi *m, const float *host_xyzm);
+int nbody_multi_set_velocities(nbody_multi *m, const float *host_xyzw);
 int nbody_multi_set_particle_softening(nbody_multi *m, const float *host_eps);
 int nbody_multi_download(nbody_multi *m, float *host_xyzm, float *host_xyzw);
 /* perm[k] = the caller's index of the body stored in slot k of the replicas (the identity with NBODY_ORDER_GIVEN); n_bodies
@@ -322,10 +372,12 @@ int nbody_multi_download(nbody_multi *m, float *host_xyzm, float *host_xyzw);
 int nbody_multi_order(nbody_multi *m, int64_t *perm);
 /* NBODY_ORDER_MORTON only (no-ops otherwise): the layout decays as the bodies move -- at N = 2^20 the first 100 steps of
  * dt = 1e-3 run 4.2 % faster than in the generator's order, steps 900-1000 1.5 % (profiles/r02_longrun_morton_decay_*).
- * nbody_multi_reorder lays a new curve through the current positions (state to the host and back: ~0.3 s at N = 2^20; the
- * kick-drift-kick mode recomputes its cached accelerations); with a period > 0 the first step that is due does it by
- * itself.  Results stay deterministic and the same for every rank count; they depend on the period (the order of the
- * sums does).  Collective in the one-rank-per-process model. */
+ * nbody_multi_reorder lays a new curve through the current positions ON THE DEVICE: every rank sorts its own replica
+ * (nbody_order_compute: the same permutation everywhere), the velocity rows are re-dealt through one gather of all rows
+ * (RCCL all-gather or peer copies), softening lengths and the order array follow; no host copy of the state (round 2 went
+ * through the host: 0.13-0.3 s at N = 2^20).  The kick-drift-kick mode recomputes its cached accelerations.  With a period
+ * > 0 the first step that is due does it by itself.  Results stay deterministic and the same for every rank count; they
+ * depend on the period (the order of the sums does).  Collective in the one-rank-per-process model. */
 int nbody_multi_reorder(nbody_multi *m);
 int nbody_multi_set_reorder_period(nbody_multi *m, int64_t steps);
 
@@ -346,6 +398,20 @@ int nbody_multi_momentum(nbody_multi *m, double *out4);
 int nbody_multi_replica_checksums(nbody_multi *m, uint64_t *out2);
 /* out8 = {n_bodies, n_padded, rows_per_rank, split_len, world_size, local ranks, ranks of the RCCL communicator, exchange} */
 int nbody_multi_info(const nbody_multi *m, int64_t *out8);
+/* Measurement: where a rank's step goes besides its kernels.  With timing on, the exchanges are bracketed by HIP events on
+ * the streams they run on (and the shard contexts time their kernels, nbody_timing_enable).  nbody_multi_timing_read waits
+ * for everything recorded, returns the totals of local rank local_index since the last read and resets them:
+ *   out16 = { steps, host milliseconds spent enqueuing them,
+ *             force kernels ms, launches,   behind-the-force-pass kernels (summation, update, kicks) ms, launches,
+ *             auxiliary-stream kernels ms, launches,
+ *             position exchange on the communication stream ms, count,
+ *             position exchange as the waiting force launch saw it -- from the end of the previous update (the moment the
+ *               launch could have started) to the arrival of the rows -- ms, count (ring: per hop),
+ *             pair-once column-sum exchange ms, count (on the compute stream: not hidden, by design),
+ *             layout refreshes ms, count }
+ * sums of event-pair durations, not wall time. */
+int nbody_multi_timing_enable(nbody_multi *m, int on);
+int nbody_multi_timing_read(nbody_multi *m, int local_index, double *out16);
 /* Local rank i's shard context (timing, device info, kernel selection) and device buffers; borrowed. */
 nbody_ctx *nbody_multi_shard(nbody_multi *m, int local_index);
 float *nbody_multi_positions_device(nbody_multi *m, int local_index);

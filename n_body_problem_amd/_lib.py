@@ -77,6 +77,20 @@ _PROTOTYPES = {
     "nbody_set_early_summation": (c_int, [c_void_p, c_int]),
     "nbody_set_summation_parts": (c_int, [c_void_p, c_int]),
     "nbody_morton_order": (c_int, [c_void_p, c_int64, c_void_p]),
+    "nbody_create_auto": (c_int, [POINTER(c_void_p), c_int, c_int64]),
+    "nbody_force_mode": (c_int, [c_void_p]),
+    "nbody_reorder": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
+    "nbody_morton_order_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nbody_order_compute": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nbody_order_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int]),
+    "nbody_order_read": (c_int, [c_void_p, c_void_p]),
+    "nbody_order_identity": (c_int, [c_void_p, c_void_p, c_int64]),
+    "nbody_order_set": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "nbody_order_permute_softening": (c_int, [c_void_p]),
+    "nbody_multi_set_positions": (c_int, [c_void_p, c_void_p]),
+    "nbody_multi_set_velocities": (c_int, [c_void_p, c_void_p]),
+    "nbody_multi_timing_enable": (c_int, [c_void_p, c_int]),
+    "nbody_multi_timing_read": (c_int, [c_void_p, c_int, POINTER(c_double)]),
     "nbody_multi_order": (c_int, [c_void_p, c_void_p]),
     "nbody_multi_reorder": (c_int, [c_void_p]),
     "nbody_multi_set_reorder_period": (c_int, [c_void_p, c_int64]),

@@ -13,7 +13,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnbody_amd.so")
-SOURCES = ["nbody_kernels.hip", "nbody_symmetric.hip", "nbody_capi.hip", "nbody_multi.hip"]
+SOURCES = ["nbody_kernels.hip", "nbody_symmetric.hip", "nbody_order.hip", "nbody_capi.hip", "nbody_multi.hip"]
 HEADERS = [os.path.join(CSRC, "nbody_kernels.h"), os.path.join(PKG_DIR, "..", "include", "nbody.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ffp-contract=off",
@@ -47,8 +47,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(PKG_DIR, "..", "build", "obj")
     os.makedirs(objdir, exist_ok=True)
     compile_flags = [f for f in FLAGS if f != "-shared"]
-    objs = []
-    for src in SOURCES:
+    def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc(), *compile_flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         res = subprocess.run(cmd, capture_output=True, text=True)
@@ -57,7 +56,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             print(res.stdout + res.stderr)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed compiling {src}:\n" + res.stderr[-4000:])
-        objs.append(obj)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:  # one hipcc per source file
+        objs = list(pool.map(compile_one, SOURCES))
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib")
     cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-L" + rocm_lib, "-lrccl", "-o", LIB_PATH]
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -92,6 +92,12 @@ struct nbody_ctx {
     double force_ms = 0, update_ms = 0, aux_ms = 0;  // aux: what the pair-once mode runs on the auxiliary stream BESIDE the
                                                       // tile launches (diagonal tiles, early summation)
     int64_t force_launches = 0, update_launches = 0, aux_launches = 0;
+    // body order on the device (nbody_order.hip): the last permutation nbody_order_compute produced, the sort's scratch and
+    // the buffer in-place gathers go through.  Allocated by the first use.
+    unsigned *order_perm = nullptr;  // [n_total]: slot k <- body order_perm[k]; the identity beyond the n of the last compute
+    int64_t order_n = -1;            // that n, or -1: no permutation yet
+    void *order_scratch = nullptr, *order_tmp = nullptr;
+    size_t order_scratch_bytes = 0, order_tmp_bytes = 0;
     std::string err;
 };
 
@@ -107,6 +113,16 @@ static int fail(nbody_ctx *c, int status, const std::string &msg)
 }
 
 static void free_sym_tiles(nbody_ctx *c);
+
+// The captured step bakes in every device pointer the launches take (partial sums, tile lists, exchange buffer): whatever
+// frees or replaces one of them drops the graph, and the next nbody_step_n captures a new one.
+static void drop_step_graph(nbody_ctx *c)
+{
+    if (c->step_graph) {
+        (void)hipGraphExecDestroy(c->step_graph);
+        c->step_graph = nullptr;
+    }
+}
 
 #define HIP_TRY(c, call)                                                                                   \
     do {                                                                                                   \
@@ -390,6 +406,23 @@ int nbody_create(nbody_ctx **out, int device, int64_t n_total)
     return nbody_create_shard(out, device, n_total, 0, n_total, 0);
 }
 
+int nbody_create_auto(nbody_ctx **out, int device, int64_t n_total)
+{
+    const bool pair_once = n_total >= NBODY_PAIR_ONCE_MIN_BODIES;
+    int rc = nbody_create_shard(out, device, n_total, 0, n_total, pair_once ? nbody_pair_once_split_len(n_total) : 0);
+    if (rc != NBODY_OK)
+        return rc;
+    rc = nbody_set_force_mode(*out, pair_once ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED);
+    if (rc != NBODY_OK) {
+        g_create_error = (*out)->err;
+        nbody_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int nbody_force_mode(const nbody_ctx *c) { return c ? c->force_mode : NBODY_ERR_INVALID; }
+
 int nbody_destroy(nbody_ctx *c)
 {
     if (!c)
@@ -417,6 +450,9 @@ int nbody_destroy(nbody_ctx *c)
     for (auto &e : c->ev_red) (void)hipEventDestroy(e);
     if (c->split_mass) (void)hipFree(c->split_mass);
     if (c->acc) (void)hipFree(c->acc);
+    if (c->order_perm) (void)hipFree(c->order_perm);
+    if (c->order_scratch) (void)hipFree(c->order_scratch);
+    if (c->order_tmp) (void)hipFree(c->order_tmp);
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -624,10 +660,48 @@ int nbody_timing_read(nbody_ctx *c, double *force_ms, int64_t *force_launches, d
 
 // ---- the step -------------------------------------------------------------------------------
 
+// A context that owns every row may change its split length while no partial sums are pending (NBODY_FORCE_AUTO: the two
+// force modes want different ones): everything sized or indexed by splits is released and rebuilt by the next force call.
+static int resplit(nbody_ctx *c, int64_t split_len)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->own_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    free_sym_tiles(c);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->col_partials) (void)hipFree(c->col_partials);
+    c->partials = nullptr;
+    c->col_partials = nullptr;
+    c->partials_entries = c->col_entries = 0;
+    c->split_len = split_len;
+    c->n_splits = (int)((c->n_total + split_len - 1) / split_len);
+    c->split_done.assign((size_t)c->n_splits, 0);
+    if (c->split_mass) (void)hipFree(c->split_mass);
+    c->split_mass = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->split_mass, sizeof(float) * (size_t)std::max(1, c->n_splits)));
+    c->force_mode = NBODY_FORCE_ONE_SIDED;  // the pair-once geometry (groups of splits) is set up again by the caller
+    c->sym_reduced = false;
+    c->acc_valid = false;
+    return NBODY_OK;
+}
+
 int nbody_set_force_mode(nbody_ctx *c, int mode)
 {
-    if (!c || (mode != NBODY_FORCE_ONE_SIDED && mode != NBODY_FORCE_SYMMETRIC))
+    if (!c || (mode != NBODY_FORCE_ONE_SIDED && mode != NBODY_FORCE_SYMMETRIC && mode != NBODY_FORCE_AUTO))
         return fail(c, NBODY_ERR_INVALID, "nbody_set_force_mode: unknown mode");
+    if (mode == NBODY_FORCE_AUTO) {  // the faster mode for this body count, with the split length that mode wants
+        if (c->row_lo != 0 || c->row_count != c->n_total)
+            return fail(c, NBODY_ERR_INVALID, "nbody_set_force_mode: NBODY_FORCE_AUTO needs a context that owns every row (the "
+                                              "split length of a shard is part of the sharding)");
+        mode = c->n_total >= NBODY_PAIR_ONCE_MIN_BODIES ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED;
+        const int64_t want = mode == NBODY_FORCE_SYMMETRIC ? nbody_pair_once_split_len(c->n_total) : nbody_default_split_len(c->n_total);
+        if (want != c->split_len) {
+            int rc = resplit(c, want);
+            if (rc != NBODY_OK)
+                return rc;
+        }
+    }
     if (mode == NBODY_FORCE_SYMMETRIC && c->force_mode != NBODY_FORCE_SYMMETRIC) {
         if (c->split_len < 256 || c->split_len > 4096)
             return fail(c, NBODY_ERR_INVALID,
@@ -670,6 +744,7 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
     c->force_mode = mode;
     std::fill(c->split_done.begin(), c->split_done.end(), 0);
     c->acc_valid = false;
+    drop_step_graph(c);
     return NBODY_OK;
 }
 
@@ -677,6 +752,7 @@ int nbody_sym_set_colparts(nbody_ctx *c, float *d_buf)
 {
     if (!c)
         return NBODY_ERR_INVALID;
+    drop_step_graph(c);
     if (d_buf) {
         c->colparts = reinterpret_cast<float4 *>(d_buf);
     } else {
@@ -798,6 +874,7 @@ static void free_sym_tiles(nbody_ctx *c)
         }
     c->sym_plans.clear();
     c->pending = nullptr;
+    drop_step_graph(c);
 }
 
 int nbody_set_summation_parts(nbody_ctx *c, int parts)
@@ -810,10 +887,6 @@ int nbody_set_summation_parts(nbody_ctx *c, int parts)
         HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
         free_sym_tiles(c);  // the cached plans carry the cut into parts
         std::fill(c->split_done.begin(), c->split_done.end(), 0);
-        if (c->step_graph) {
-            (void)hipGraphExecDestroy(c->step_graph);
-            c->step_graph = nullptr;
-        }
     }
     c->sum_parts = parts;
     c->acc_valid = false;
@@ -829,8 +902,8 @@ int64_t nbody_partial_sum_bytes(const nbody_ctx *c)
 
 int nbody_set_rows_per_lane(nbody_ctx *c, int rpl)
 {
-    if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == -4 || rpl == 8 || rpl == 40))
-        return fail(c, NBODY_ERR_INVALID, "nbody_set_rows_per_lane: expected 0, 1, 2, 4, 8, -4 or 40");
+    if (!c || !(rpl == 0 || rpl == 1 || rpl == 2 || rpl == 4 || rpl == -4 || rpl == 8 || rpl == 40 || rpl == 41))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_rows_per_lane: expected 0, 1, 2, 4, 8, -4, 40 or 41");
     c->rows_per_lane = rpl;
     return NBODY_OK;
 }
@@ -846,13 +919,18 @@ static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
         return c->rows_per_lane;
     const bool short_splits = c->split_len <= 512;
     const int64_t want[2] = {(short_splits ? 10LL : 4LL) * c->cu_count, (short_splits ? 20LL : 4LL) * c->cu_count};
-    int i = 0;
-    for (int rpl : {4, 2}) {
-        int64_t blocks = (c->row_count + (int64_t)kTile * rpl - 1) / ((int64_t)kTile * rpl) * split_count;
-        if (blocks >= want[i++])
-            return rpl;
-    }
-    return 1;
+    const int64_t blocks4 = (c->row_count + (int64_t)kTile * 4 - 1) / ((int64_t)kTile * 4) * split_count;
+    if (blocks4 >= want[0])
+        return 4;
+    // too few 1024-row workgroups: the same packed loop with one wave (256 rows) per workgroup, once there are about three
+    // waves per SIMD to deal out (N = 20 225: 6320 waves, 90 against 124 us per pass with one row per lane); below that the
+    // one-row kernel spreads a small system over more SIMDs (profiles/r03_small_n_blocking.txt)
+    static const int64_t w1_min = getenv("NBODY_W1_MIN_WAVES") ? atoll(getenv("NBODY_W1_MIN_WAVES")) : 12;
+    const int64_t waves1 = (c->row_count + kTile - 1) / kTile * split_count;
+    if (!c->eps_pp && waves1 >= w1_min * c->cu_count)
+        return 41;
+    const int64_t blocks2 = (c->row_count + (int64_t)kTile * 2 - 1) / ((int64_t)kTile * 2) * split_count;
+    return blocks2 >= want[1] ? 2 : 1;
 }
 
 // The partial-sum array of the one-sided mode (a mode switch may need a larger one).
@@ -862,8 +940,10 @@ static int ensure_partials(nbody_ctx *c)
     if (entries <= c->partials_entries)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    drop_step_graph(c);  // a captured step would keep launching on the array freed here
     if (c->partials) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->own_stream));
         (void)hipFree(c->partials);
         c->partials = nullptr;
         c->partials_entries = 0;
@@ -883,7 +963,9 @@ static int ensure_sym_buffers(nbody_ctx *c, size_t row_entries, size_t col_entri
     if (row_f4 <= c->partials_entries && col_entries <= c->col_entries)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    drop_step_graph(c);  // a captured step would keep launching on the arrays freed here
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->own_stream));
     HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     if (row_f4 > c->partials_entries) {
         if (c->partials)
@@ -1169,10 +1251,14 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
     if (a.split_count <= 0)
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, launch_split_mass(a.pos, c->split_mass, a.n_total, a.split_len, c->equal_mass_path, c->stream));
+    const int rpl = pick_rows_per_lane(c, a.split_count);
+    // the one-wave kernel forms the equal-mass flag of a one-tile split from the tile it holds: no launch in front
+    a.own_split_mass = rpl == 41 && a.split_len == kTile && !a.eps_pp && c->equal_mass_path;
+    if (!a.own_split_mass)
+        HIP_TRY(c, launch_split_mass(a.pos, c->split_mass, a.n_total, a.split_len, c->equal_mass_path, c->stream));
     {
         TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);
-        HIP_TRY(c, launch_forces(a, pick_rows_per_lane(c, a.split_count), c->stream));
+        HIP_TRY(c, launch_forces(a, rpl, c->stream));
     }
     for (int s = 0; s < c->n_splits; ++s)
         if ((s >= first && s < first + count) != complement)
@@ -1460,6 +1546,161 @@ int nbody_step_n_on(nbody_ctx *c, float *d_pos, float *d_vel, int k, float dt, f
             return rc;
     }
     return nbody_sync(c);
+}
+
+// ---- body order on the device (nbody_order.hip) -------------------------------------------------------------------
+
+static int ensure_order_buffers(nbody_ctx *c, size_t tmp_bytes)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->order_perm && c->n_total)
+        HIP_TRY(c, hipMalloc((void **)&c->order_perm, sizeof(unsigned) * (size_t)c->n_total));
+    const size_t need = order_scratch_bytes((int)c->n_total);
+    if (need > c->order_scratch_bytes) {
+        if (c->order_scratch) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->order_scratch);
+        }
+        c->order_scratch = nullptr;
+        c->order_scratch_bytes = 0;
+        HIP_TRY(c, hipMalloc(&c->order_scratch, need));
+        c->order_scratch_bytes = need;
+    }
+    if (tmp_bytes > c->order_tmp_bytes) {
+        if (c->order_tmp) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->order_tmp);
+        }
+        c->order_tmp = nullptr;
+        c->order_tmp_bytes = 0;
+        HIP_TRY(c, hipMalloc(&c->order_tmp, tmp_bytes));
+        c->order_tmp_bytes = tmp_bytes;
+    }
+    return NBODY_OK;
+}
+
+int nbody_order_compute(nbody_ctx *c, const float *d_xyzm, int64_t n, const int64_t *d_order)
+{
+    if (!c || n < 0 || n > c->n_total || (n > 0 && !d_xyzm))
+        return fail(c, NBODY_ERR_INVALID, "nbody_order_compute: expected 0 <= n <= n_total bodies on the device");
+    int rc = ensure_order_buffers(c, 0);
+    if (rc != NBODY_OK)
+        return rc;
+    HIP_TRY(c, launch_morton_order(reinterpret_cast<const float4 *>(d_xyzm), (int)n, c->order_perm, c->order_scratch, c->stream,
+                                   d_order));
+    HIP_TRY(c, launch_identity_perm(c->order_perm, (int)n, (int)(c->n_total - n), c->stream));
+    c->order_n = n;
+    return NBODY_OK;
+}
+
+int nbody_order_gather(nbody_ctx *c, void *d_dst, const void *d_src, int64_t first, int64_t count, int floats_per_row)
+{
+    if (!c || first < 0 || count < 0 || first + count > c->n_total || (count > 0 && (!d_dst || !d_src)) ||
+        !(floats_per_row == 1 || floats_per_row == 2 || floats_per_row == 4))
+        return fail(c, NBODY_ERR_INVALID, "nbody_order_gather: rows [first, first + count) inside [0, n_total), 1, 2 or 4 floats a row");
+    if (c->order_n < 0)
+        return fail(c, NBODY_ERR_STATE, "nbody_order_gather: no permutation (nbody_order_compute first)");
+    if (count == 0)
+        return NBODY_OK;
+    const bool in_place = d_dst == d_src;
+    if (in_place && first != 0)
+        return fail(c, NBODY_ERR_INVALID, "nbody_order_gather: in place only from row 0 (the source is indexed by body)");
+    const size_t bytes = (size_t)count * (size_t)floats_per_row * sizeof(float);
+    void *dst = d_dst;
+    if (in_place) {
+        int rc = ensure_order_buffers(c, bytes);
+        if (rc != NBODY_OK)
+            return rc;
+        dst = c->order_tmp;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (floats_per_row == 4)
+        HIP_TRY(c, launch_gather_float4(static_cast<float4 *>(dst), static_cast<const float4 *>(d_src), c->order_perm, (int)first,
+                                        (int)count, c->stream));
+    else if (floats_per_row == 2)
+        HIP_TRY(c, launch_gather_int64(static_cast<int64_t *>(dst), static_cast<const int64_t *>(d_src), c->order_perm, (int)first,
+                                       (int)count, c->stream));
+    else
+        HIP_TRY(c, launch_gather_float(static_cast<float *>(dst), static_cast<const float *>(d_src), c->order_perm, (int)first,
+                                       (int)count, c->stream));
+    if (in_place)
+        HIP_TRY(c, hipMemcpyAsync(d_dst, dst, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return NBODY_OK;
+}
+
+int nbody_order_read(nbody_ctx *c, int64_t *d_perm)
+{
+    if (!c || (c->order_n > 0 && !d_perm))
+        return fail(c, NBODY_ERR_INVALID, "nbody_order_read: NULL argument");
+    if (c->order_n < 0)
+        return fail(c, NBODY_ERR_STATE, "nbody_order_read: no permutation (nbody_order_compute first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_widen_perm(d_perm, c->order_perm, (int)c->order_n, c->stream));
+    return NBODY_OK;
+}
+
+int nbody_order_set(nbody_ctx *c, const int64_t *d_order, int64_t n, int inverse)
+{
+    if (!c || n < 0 || n > c->n_total || (n > 0 && !d_order))
+        return fail(c, NBODY_ERR_INVALID, "nbody_order_set: expected 0 <= n <= n_total indices on the device");
+    int rc = ensure_order_buffers(c, 0);
+    if (rc != NBODY_OK)
+        return rc;
+    HIP_TRY(c, launch_set_perm(c->order_perm, d_order, (int)n, inverse != 0, c->stream));
+    HIP_TRY(c, launch_identity_perm(c->order_perm, (int)n, (int)(c->n_total - n), c->stream));
+    c->order_n = n;
+    return NBODY_OK;
+}
+
+int nbody_order_identity(nbody_ctx *c, int64_t *d_order, int64_t n)
+{
+    if (!c || n < 0 || (n > 0 && !d_order))
+        return fail(c, NBODY_ERR_INVALID, "nbody_order_identity: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_iota64(d_order, (int)n, c->stream));
+    return NBODY_OK;
+}
+
+int nbody_order_permute_softening(nbody_ctx *c)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    if (!c->eps_own || c->eps_pp != c->eps_own)
+        return NBODY_OK;  // no copy of its own in use: a borrowed array is the caller's to permute (nbody_order_gather)
+    c->acc_valid = false;
+    return nbody_order_gather(c, c->eps_own, c->eps_own, 0, c->n_total, 1);
+}
+
+int nbody_morton_order_device(nbody_ctx *c, const float *d_xyzm, int64_t n, int64_t *d_perm)
+{
+    int rc = nbody_order_compute(c, d_xyzm, n, nullptr);
+    return rc == NBODY_OK ? nbody_order_read(c, d_perm) : rc;
+}
+
+int nbody_reorder(nbody_ctx *c, float *d_pos, float *d_vel, float *d_eps, int64_t *d_order, int64_t n)
+{
+    if (!c)
+        return NBODY_ERR_INVALID;
+    if (c->row_lo != 0 || c->row_count != c->n_total)
+        return fail(c, NBODY_ERR_INVALID, "nbody_reorder: the context must own every row (shards: nbody_multi_reorder)");
+    if (n < 0 || n > c->n_total || (n > 0 && (!d_pos || !d_vel)))
+        return fail(c, NBODY_ERR_INVALID, "nbody_reorder: expected 0 <= n <= n_total and device positions and velocities");
+    if (n == 0)
+        return NBODY_OK;
+    int rc = nbody_order_compute(c, d_pos, n, d_order);
+    if (rc == NBODY_OK)
+        rc = nbody_order_gather(c, d_pos, d_pos, 0, n, 4);
+    if (rc == NBODY_OK)
+        rc = nbody_order_gather(c, d_vel, d_vel, 0, n, 4);
+    if (rc == NBODY_OK && d_eps)
+        rc = nbody_order_gather(c, d_eps, d_eps, 0, n, 1);
+    if (rc == NBODY_OK && d_eps != c->eps_own)
+        rc = nbody_order_permute_softening(c);
+    if (rc == NBODY_OK && d_order)
+        rc = nbody_order_gather(c, d_order, d_order, 0, n, 2);
+    if (rc == NBODY_OK)
+        rc = nbody_invalidate_forces(c);
+    return rc;
 }
 
 // ---- diagnostics ----------------------------------------------------------------------------

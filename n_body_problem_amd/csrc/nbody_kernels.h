@@ -33,6 +33,7 @@ struct ForceArgs {
     float eps2;          // softening length squared
     const float *eps_pp; // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
     const float *split_mass;  // [n_splits]: the one mass of a split's bodies, or NaN (launch_split_mass)
+    int own_split_mass;       // force_kernel_r4pk_w1, one-tile splits: the kernel forms that flag itself (nothing was launched)
 };
 
 // Pair-once kernel (nbody_symmetric.hip): one workgroup per ordered pair of splits (R, C), R's bodies as rows (one
@@ -127,5 +128,22 @@ int energy_kernel_blocks(int row_count);  // blocks of launch_energy (four rows 
 // Per-block {px,py,pz,m} doubles into block_out[4*gridDim.x].
 hipError_t launch_momentum(const float4 *pos_all, const float4 *vel_rows, double *block_out, int row_lo,
                            int row_count, hipStream_t stream);
+
+// ---- body order on the device (nbody_order.hip) ----------------------------------------------------------------------
+// perm[k] (k < n) = the slot whose body belongs at slot k (nbody_morton_order), as 32-bit indices; scratch holds
+// order_scratch_bytes(n).
+size_t order_scratch_bytes(int n);
+// order (n int64 on the device, or NULL): the caller's index of the body in each slot -- ties between equal keys follow it
+hipError_t launch_morton_order(const float4 *pos, int n, unsigned *perm, void *scratch, hipStream_t stream,
+                               const int64_t *order = nullptr);
+hipError_t launch_identity_perm(unsigned *perm, int first, int count, hipStream_t stream);  // perm[first + j] = first + j
+// dst[j] = src[perm[first + j]], j < count
+hipError_t launch_gather_float4(float4 *dst, const float4 *src, const unsigned *perm, int first, int count, hipStream_t stream);
+hipError_t launch_gather_float(float *dst, const float *src, const unsigned *perm, int first, int count, hipStream_t stream);
+hipError_t launch_gather_int64(int64_t *dst, const int64_t *src, const unsigned *perm, int first, int count, hipStream_t stream);
+hipError_t launch_widen_perm(int64_t *dst, const unsigned *src, int n, hipStream_t stream);
+hipError_t launch_iota64(int64_t *dst, int n, hipStream_t stream);
+// perm[k] = order[k] (k < n), or the inverse: perm[order[k]] = k (order must then be a permutation of 0..n-1)
+hipError_t launch_set_perm(unsigned *perm, const int64_t *order, int n, bool inverse, hipStream_t stream);
 
 }  // namespace nbody

@@ -461,6 +461,129 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
     if (row_base + 3 * kTile < a.row_count) out[row_base + 3 * kTile] = make_float4(ax23.y * sc, ay23.y * sc, az23.y * sc, 0.f);
 }
 
+// ---- the same packed loop with ONE wave per workgroup: systems too small to fill the chip with 1024-row workgroups ------
+// A workgroup of the kernel above is 4 waves x 4 rows x 64 lanes = 1024 rows: at the reference's own size (20 225 bodies
+// padded, 79 splits of 256 columns) that is 20 x 79 = 1580 workgroups, six or seven to a CU, and the compiler-allocated
+// one-row kernel that filled the chip better ran at 3.3e12 interactions/s (124 us per pass, profiles/r03_small_n_kernels.txt)
+// against the 4.8e12 this loop reaches on large systems.  Here a workgroup is one wave: 256 rows x one split, 80 x 79 = 6320
+// waves, six to a SIMD, dealt as slots free up; the wave stages its own 256-column tiles (four float4 a lane, no barrier
+// partner) and runs the identical hand-allocated loop, so each row's sum is the same FMA chain: not a bit changes.
+// Splits of exactly one tile (split_len = 256, every system below 32 768 bodies) need no split_mass_kernel launch in front:
+// the wave holds the split's 256 masses in registers and forms the same flag itself (one launch less per step).
+template <bool GUARD>
+__global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
+{
+    __shared__ float4 tile[2 * kTile + 1];
+
+    const int lane = threadIdx.x;
+    int split = a.split_first + blockIdx.y;
+    if (split >= a.skip_first)
+        split += a.skip_count;
+    const int j0 = split * a.split_len;
+    const int j1 = min(j0 + a.split_len, a.n_total);
+    const int ntiles = (j1 - j0 + kTile - 1) / kTile;
+    const int row_base = blockIdx.x * kTile + 4 * (lane & 15) + (lane >> 4);  // rows row_base + 64 k: see force_kernel_r4pk
+
+    float4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = row_base + k * 64;
+        p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < a.row_count)
+            p[k] = a.pos[a.row_lo + r];
+    }
+    const nb_f2 x01 = {p[0].x, p[1].x}, y01 = {p[0].y, p[1].y}, z01 = {p[0].z, p[1].z};
+    const nb_f2 x23 = {p[2].x, p[3].x}, y23 = {p[2].y, p[3].y}, z23 = {p[2].z, p[3].z};
+    nb_f2 ax01 = {0.f, 0.f}, ay01 = ax01, az01 = ax01, ax23 = ax01, ay23 = ax01, az23 = ax01;
+    const nb_f2 epsv = {a.eps2, 0.f};
+    const float tiny = kGuardMin, pinf = __builtin_inff();
+
+    float4 stage[4];  // four columns of the tile per lane; an out-of-range column is a zero-mass body at the origin
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = j0 + k * 64 + lane;
+        stage[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < j1)
+            stage[k] = a.pos[c];
+    }
+    // the one mass of the split's bodies, as split_mass_kernel defines it (nbody_symmetric.hip): from the tile in registers
+    // when the split is this one tile, else from the flags the launch in front has written
+    float split_mass = __builtin_nanf("");
+    if (!GUARD) {
+        if (a.own_split_mass) {
+            const unsigned m0 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, stage[0].w));
+            bool differs = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                differs |= __builtin_bit_cast(unsigned, stage[k].w) != m0;
+            const float mf = __builtin_bit_cast(float, m0);
+            if (!__builtin_amdgcn_ballot_w64(differs) && fabsf(mf) <= 3.4e38f)
+                split_mass = mf;
+        } else {
+            split_mass = a.split_mass[split];
+        }
+    }
+    const bool uniform = split_mass == split_mass;
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        tile[k * 64 + lane] = stage[k];
+    if (lane == 0)
+        tile[2 * kTile] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) {  // in flight under the tile's arithmetic
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = j0 + (t + 1) * kTile + k * 64 + lane;
+                stage[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < j1)
+                    stage[k] = a.pos[c];
+            }
+        }
+        unsigned lds = (unsigned)(size_t)(&tile[(t & 1) * kTile]);
+        unsigned cnt;
+#define PK_OPERANDS                                                                                                   \
+        : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),          \
+          "+{v[48:49]}"(az23), "+{v52}"(lds), [cnt] "=&s"(cnt)                                                            \
+        : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23), "{v[16:17]}"(z23),  \
+          "{v[8:9]}"(epsv), "{v10}"(tiny), "{v11}"(pinf)                                                                  \
+        : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35", "v38",   \
+          "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "vcc", "memory"
+        if (GUARD)
+            asm volatile(PK_TILE_LOOP(PK_GUARD, PK_POST) PK_OPERANDS);
+        else if (uniform)
+            asm volatile(PK_TILE_LOOP(PK_NOGUARD, PK_POSTU) PK_OPERANDS);
+        else
+            asm volatile(PK_TILE_LOOP(PK_NOGUARD, PK_POST) PK_OPERANDS);
+#undef PK_OPERANDS
+        if (t + 1 < ntiles) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                tile[((t + 1) & 1) * kTile + k * 64 + lane] = stage[k];
+        }
+        __syncthreads();
+    }
+
+    float4 *out = a.partials + (size_t)split * a.row_count;
+    const float sc = uniform ? split_mass : 1.f;
+    if (row_base < a.row_count) out[row_base] = make_float4(ax01.x * sc, ay01.x * sc, az01.x * sc, 0.f);
+    if (row_base + 64 < a.row_count) out[row_base + 64] = make_float4(ax01.y * sc, ay01.y * sc, az01.y * sc, 0.f);
+    if (row_base + 128 < a.row_count) out[row_base + 128] = make_float4(ax23.x * sc, ay23.x * sc, az23.x * sc, 0.f);
+    if (row_base + 192 < a.row_count) out[row_base + 192] = make_float4(ax23.y * sc, ay23.y * sc, az23.y * sc, 0.f);
+}
+
+static hipError_t launch_forces_r4pk_w1(const ForceArgs &a, hipStream_t stream)
+{
+    dim3 grid((a.row_count + kTile - 1) / kTile, a.split_count, 1);
+    if (a.eps2 > 0.f)
+        hipLaunchKernelGGL(force_kernel_r4pk_w1<false>, grid, dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL(force_kernel_r4pk_w1<true>, grid, dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
 static hipError_t launch_forces_r4pk(const ForceArgs &a, hipStream_t stream)
 {
     dim3 grid((a.row_count + kTile * 4 - 1) / (kTile * 4), a.split_count, 1);
@@ -500,7 +623,8 @@ static hipError_t launch_forces_r4_asm(const ForceArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-// rows_per_lane: 4 = the hand-allocated kernel (default), 1/2/8 and -4 = the compiler-allocated template
+// rows_per_lane: 4 = the hand-allocated kernel (default), 41 = the same with one wave per workgroup (small systems), 1/2/8 and
+// -4 = the compiler-allocated template
 hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stream)
 {
     if (a.row_count <= 0 || a.split_count <= 0)
@@ -510,16 +634,34 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
     case 2: return launch_forces_rpl<2>(a, stream);
     case 4: return a.eps_pp ? launch_forces_rpl<4>(a, stream) : launch_forces_r4pk(a, stream);     // packed fp32 (default)
     case 40: return a.eps_pp ? launch_forces_rpl<4>(a, stream) : launch_forces_r4_asm(a, stream);  // one row per instruction
+    case 41: return a.eps_pp ? launch_forces_rpl<1>(a, stream) : launch_forces_r4pk_w1(a, stream);  // packed, one wave per workgroup
     case -4: return launch_forces_rpl<4>(a, stream);
     case 8: return launch_forces_rpl<8>(a, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
+// The splits' partial sums of row r, added in ascending split order (one fp32 chain: the order defines the bits).  The
+// loads of 16 splits are issued together and the adds follow in order: a lane's loads are independent, its adds are not,
+// and with few rows (the reference's N = 20 000: 79 splits x 20 225 rows, 80 workgroups of 256) the kernel is bound by
+// load latency, not bandwidth -- 21.7 us with one load in flight per lane, profiles/r03_small_n_kernels.txt.
 __device__ __forceinline__ float4 sum_partials(const float4 *partials, int r, int row_count, int n_splits)
 {
     float4 acc = partials[r];
-    for (int s = 1; s < n_splits; ++s) {
+    int s = 1;
+    for (; s + 16 <= n_splits; s += 16) {
+        float4 p[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            p[k] = partials[(size_t)(s + k) * row_count + r];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            acc.x += p[k].x;
+            acc.y += p[k].y;
+            acc.z += p[k].z;
+        }
+    }
+    for (; s < n_splits; ++s) {
         const float4 p = partials[(size_t)s * row_count + r];
         acc.x += p.x;
         acc.y += p.y;
@@ -530,10 +672,11 @@ __device__ __forceinline__ float4 sum_partials(const float4 *partials, int r, in
 
 // use_acc_update_position, kernel.cu:777-801, with the reference's fp64 FMA (TIME_TICK is a double
 // literal there) and the partial sums of the splits added first, in ascending split order.
-__global__ __launch_bounds__(kTile) void update_kernel(float4 *pos_all, float4 *vel_rows, const float4 *partials,
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void update_kernel(float4 *pos_all, float4 *vel_rows, const float4 *partials,
                                                        int row_lo, int row_count, int n_splits, float dt)
 {
-    const int r = blockIdx.x * kTile + threadIdx.x;
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= row_count)
         return;
     const float4 acc = sum_partials(partials, r, row_count, n_splits);
@@ -555,8 +698,13 @@ hipError_t launch_update(float4 *pos_all, float4 *vel_rows, const float4 *partia
 {
     if (row_count <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(update_kernel, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, pos_all,
-                       vel_rows, partials, row_lo, row_count, n_splits, dt);
+    // few rows: one wave per workgroup, so that every CU gets some (20 225 rows: 317 workgroups instead of 80)
+    if (row_count < 256 * kTile)
+        hipLaunchKernelGGL(update_kernel<64>, dim3((row_count + 63) / 64), dim3(64), 0, stream, pos_all, vel_rows, partials,
+                           row_lo, row_count, n_splits, dt);
+    else
+        hipLaunchKernelGGL(update_kernel<kTile>, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, pos_all,
+                           vel_rows, partials, row_lo, row_count, n_splits, dt);
     return hipGetLastError();
 }
 

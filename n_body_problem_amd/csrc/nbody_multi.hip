@@ -29,10 +29,12 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,7 +58,23 @@ struct Rank {
     std::vector<hipEvent_t> ev_hop;  // ring: hop h has been sent by this rank (PEER) / has landed at this rank (RCCL)
     std::vector<hipEvent_t> ev_step; // nbody_multi_step_n: the end of the last kStepsInFlight steps on the compute stream
     unsigned long long *scratch = nullptr;  // 4 x 8 bytes on the device (checksum, all-reduce staging)
+    float *vel_all = nullptr;      // n_padded x float4: every rank's velocity rows (layout refresh, multi-process download)
+    int64_t *order_dev = nullptr;  // NBODY_ORDER_MORTON: slot k of the replica holds the caller's body order_dev[k] (n_bodies)
+    hipEvent_t ev_vel = nullptr;   // on the comm stream: this rank's part of a velocity gather has been enqueued / has landed
+    // measurement (nbody_multi_timing_*): event pairs not yet added to the totals, by kind
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    double span_ms[4] = {0, 0, 0, 0};
+    int64_t span_count[4] = {0, 0, 0, 0};
+    double host_ms = 0;
+    int64_t steps = 0;
 };
+
+enum { kSpanPosComm = 0,   // comm stream: the position exchange from the moment it may start to its arrival
+       kSpanPosWait = 1,   // consumer stream: from the moment the waiting force launch could have started to the arrival
+       kSpanColumns = 2,   // compute stream: the pair-once column-sum exchange (not hidden by design)
+       kSpanReorder = 3 }; // compute stream: a layout refresh
 
 }  // namespace
 
@@ -68,7 +86,9 @@ struct nbody_multi {
     int64_t n_bodies = 0, n_padded = 0, chunk = 0, split_len = 0;
     std::vector<Rank> ranks;  // the local ranks
     Channel ch_pos, ch_col;
-    std::vector<int64_t> order;  // NBODY_ORDER_MORTON: slot k of the replicas holds the caller's body order[k] (set by set_state)
+    std::vector<int64_t> order;  // NBODY_ORDER_MORTON: host copy of Rank::order_dev, valid while order_host_valid (the
+                                 // layout is refreshed on the device; the host asks for the order when it needs it)
+    bool order_host_valid = false;
     std::vector<float> eps_caller;             // the per-particle softening lengths as given (the caller's order), or empty
     bool eps_on = false;
     int64_t reorder_period = 0, steps_since_order = 0;  // NBODY_ORDER_MORTON: refresh the layout every so many steps (0: never)
@@ -76,7 +96,8 @@ struct nbody_multi {
     bool kdk_ready = false;
     bool have_state = false;
     double timeout_s = 600.0;  // per wait: a wait never covers more than kStepsInFlight steps
-    float *gather_vel = nullptr;  // multi-process download: all velocities, on the first local device
+    bool timing = false;       // nbody_multi_timing_enable
+    bool failed = false;       // an exchange failed or timed out: the communicators are gone, destroy must not wait for peers
     std::string err;
 };
 
@@ -89,6 +110,27 @@ static int mfail(nbody_multi *m, int status, const std::string &msg)
     else
         g_multi_create_error = msg;
     return status;
+}
+
+// Nothing is thrown across the C ABI: the entry points that build host vectors and strings run inside this.
+template <class F>
+static int guarded(nbody_multi *m, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try {
+            return mfail(m, NBODY_ERR_ALLOC, "host allocation failed");
+        } catch (...) {
+            return NBODY_ERR_ALLOC;
+        }
+    } catch (...) {
+        try {
+            return mfail(m, NBODY_ERR_DEVICE, "unexpected C++ exception");
+        } catch (...) {
+            return NBODY_ERR_DEVICE;
+        }
+    }
 }
 
 #define MHIP(m, call)                                                                                          \
@@ -213,7 +255,15 @@ static int setup_ranks(nbody_multi *m)
         MCTX(m, r, nbody_set_integrator(r.ctx, m->cfg.integrator));
         MHIP(m, hipStreamCreateWithFlags(&r.compute, hipStreamNonBlocking));
         MHIP(m, hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
-        MHIP(m, hipStreamCreateWithFlags(&r.comm, hipStreamNonBlocking));
+        // The exchange's kernels (RCCL's, or the copy engine's fallbacks) must win CUs from a force launch that fills every
+        // CU with 0.6 ms workgroups, and the complement launch waits for them: the communication stream gets the highest
+        // priority the device offers (NBODY_COMM_PRIORITY=0: the default priority, for A/B measurement).
+        {
+            static const bool high = !(getenv("NBODY_COMM_PRIORITY") && atoi(getenv("NBODY_COMM_PRIORITY")) == 0);
+            int least = 0, greatest = 0;
+            MHIP(m, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            MHIP(m, hipStreamCreateWithPriority(&r.comm, hipStreamNonBlocking, high ? greatest : 0));
+        }
         if (m->n_padded) {
             MHIP(m, hipMalloc((void **)&r.pos, sizeof(float) * 4 * (size_t)m->n_padded));
             MHIP(m, hipMemsetAsync(r.pos, 0, sizeof(float) * 4 * (size_t)m->n_padded, r.compute));
@@ -225,9 +275,14 @@ static int setup_ranks(nbody_multi *m)
             MHIP(m, hipMalloc((void **)&r.colparts, sizeof(float) * 4 * (size_t)NBODY_SYM_GROUPS * (size_t)m->n_padded));
             MCTX(m, r, nbody_sym_set_colparts(r.ctx, r.colparts));
         }
-        for (hipEvent_t *e : {&r.ev_start, &r.ev_side, &m->ch_pos.ready[i], &m->ch_pos.done[i], &m->ch_col.ready[i],
+        for (hipEvent_t *e : {&r.ev_start, &r.ev_side, &r.ev_vel, &m->ch_pos.ready[i], &m->ch_pos.done[i], &m->ch_col.ready[i],
                               &m->ch_col.done[i]})
             MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (m->cfg.body_order == NBODY_ORDER_MORTON && m->n_bodies) {
+            MHIP(m, hipMalloc((void **)&r.order_dev, sizeof(int64_t) * (size_t)m->n_bodies));
+            MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+            MCTX(m, r, nbody_order_identity(r.ctx, r.order_dev, m->n_bodies));
+        }
         int rc = make_events(m, r.ev_hop, (size_t)m->world);
         if (rc == NBODY_OK)
             rc = make_events(m, r.ev_step, (size_t)kStepsInFlight);
@@ -259,8 +314,12 @@ static int create_common(nbody_multi **out, const nbody_multi_config *cfg, int w
         (cfg->exchange != NBODY_EXCHANGE_ALLGATHER && cfg->exchange != NBODY_EXCHANGE_RING) ||
         (cfg->transport != NBODY_TRANSPORT_RCCL && cfg->transport != NBODY_TRANSPORT_PEER_COPY))
         return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: unknown integrator, exchange or transport");
+    int force_mode = cfg->force_mode;
+    if (force_mode == NBODY_FORCE_AUTO)  // the pair-once kernels where they are faster and the rank count allows them
+        force_mode = cfg->n_bodies >= NBODY_PAIR_ONCE_MIN_BODIES && NBODY_SYM_GROUPS % world == 0 ? NBODY_FORCE_SYMMETRIC
+                                                                                                  : NBODY_FORCE_ONE_SIDED;
     int64_t padded = 0, chunk = 0, split = 0;
-    if (nbody_multi_geometry(cfg->n_bodies, world, cfg->force_mode, cfg->split_len, &padded, &chunk, &split) != NBODY_OK)
+    if (nbody_multi_geometry(cfg->n_bodies, world, force_mode, cfg->split_len, &padded, &chunk, &split) != NBODY_OK)
         return mfail(nullptr, NBODY_ERR_INVALID,
                      "nbody_multi_create: bad geometry (n_bodies >= 0, split_len a multiple of 256, and the pair-once mode "
                      "shards over 1, 2, 4 or 8 ranks)");
@@ -273,6 +332,7 @@ static int create_common(nbody_multi **out, const nbody_multi_config *cfg, int w
     if (!m)
         return mfail(nullptr, NBODY_ERR_ALLOC, "nbody_multi_create: host allocation failed");
     m->cfg = *cfg;
+    m->cfg.force_mode = force_mode;
     m->world = world;
     m->n_bodies = cfg->n_bodies;
     m->n_padded = padded;
@@ -367,15 +427,45 @@ extern "C" int nbody_multi_create_rank(nbody_multi **out, const nbody_multi_conf
     return NBODY_OK;
 }
 
+// Drains the local streams for at most `seconds`: false when something is still running then (a peer that will never answer).
+static bool drain_streams(nbody_multi *m, double seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        bool busy = false;
+        for (Rank &r : m->ranks) {
+            (void)hipSetDevice(r.device);
+            for (hipStream_t s : {r.compute, r.side, r.comm})
+                if (s && hipStreamQuery(s) == hipErrorNotReady)
+                    busy = true;
+        }
+        if (!busy)
+            return true;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
+            return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
+static void abort_communicators(nbody_multi *m)
+{
+    for (Rank &r : m->ranks)
+        if (r.nccl) {
+            (void)ncclCommAbort(r.nccl);
+            r.nccl = nullptr;
+        }
+    m->failed = true;
+}
+
 extern "C" int nbody_multi_destroy(nbody_multi *m)
 {
     if (!m)
         return NBODY_OK;
-    for (Rank &r : m->ranks) {
-        (void)hipSetDevice(r.device);
-        for (hipStream_t s : {r.compute, r.side, r.comm})
-            if (s)
-                (void)hipStreamSynchronize(s);
+    // No unbounded wait on a peer: after a failure the communicators are already gone; otherwise the streams get the
+    // exchange timeout (at most a minute) to drain, and what is still stuck then is aborted instead of destroyed.
+    if (!drain_streams(m, m->failed ? 5.0 : std::min(m->timeout_s, 60.0))) {
+        abort_communicators(m);
+        (void)drain_streams(m, 5.0);
     }
     for (size_t i = 0; i < m->ranks.size(); ++i) {
         Rank &r = m->ranks[i];
@@ -384,12 +474,20 @@ extern "C" int nbody_multi_destroy(nbody_multi *m)
             (void)ncclCommDestroy(r.nccl);
         if (r.ctx)
             nbody_destroy(r.ctx);
-        for (float *p : {r.pos, r.vel, r.colparts})
+        for (float *p : {r.pos, r.vel, r.colparts, r.vel_all})
             if (p)
                 (void)hipFree(p);
+        if (r.order_dev)
+            (void)hipFree(r.order_dev);
         if (r.scratch)
             (void)hipFree(r.scratch);
-        for (hipEvent_t e : {r.ev_start, r.ev_side})
+        for (Rank::Span &sp : r.spans) {
+            (void)hipEventDestroy(sp.a);
+            (void)hipEventDestroy(sp.b);
+        }
+        for (hipEvent_t e : r.ev_pool)
+            (void)hipEventDestroy(e);
+        for (hipEvent_t e : {r.ev_start, r.ev_side, r.ev_vel})
             if (e)
                 (void)hipEventDestroy(e);
         for (hipEvent_t e : r.ev_hop)
@@ -406,10 +504,6 @@ extern "C" int nbody_multi_destroy(nbody_multi *m)
             if (s)
                 (void)hipStreamDestroy(s);
     }
-    if (m->gather_vel) {
-        (void)hipSetDevice(m->ranks[0].device);
-        (void)hipFree(m->gather_vel);
-    }
     delete m;
     return NBODY_OK;
 }
@@ -417,6 +511,7 @@ extern "C" int nbody_multi_destroy(nbody_multi *m)
 // ---- waiting, with failure detection ---------------------------------------------------------------------------------
 
 static int timed_out(nbody_multi *m, double waited);
+static void abort_communicators(nbody_multi *m);
 
 static int poll_async_errors(nbody_multi *m)
 {
@@ -426,8 +521,10 @@ static int poll_async_errors(nbody_multi *m)
             ncclResult_t q = ncclCommGetAsyncError(r.nccl, &async);
             if (q != ncclSuccess || (async != ncclSuccess && async != ncclInProgress)) {
                 const ncclResult_t bad = q != ncclSuccess ? q : async;
-                return mfail(m, NBODY_ERR_DEVICE, "RCCL reported an asynchronous error on rank " + std::to_string(r.rank) + ": " +
-                                                      ncclGetErrorString(bad) + " (" + ncclGetLastError(r.nccl) + ")");
+                const std::string what = "RCCL reported an asynchronous error on rank " + std::to_string(r.rank) + ": " +
+                                         ncclGetErrorString(bad) + " (" + ncclGetLastError(r.nccl) + "); the communicators were aborted";
+                abort_communicators(m);  // nothing may wait for the peers any more, nbody_multi_destroy included
+                return mfail(m, NBODY_ERR_DEVICE, what);
             }
         }
     return NBODY_OK;
@@ -472,11 +569,7 @@ static int wait_all(nbody_multi *m)
 
 static int timed_out(nbody_multi *m, double waited)
 {
-    for (Rank &r : m->ranks)
-        if (r.nccl) {
-            (void)ncclCommAbort(r.nccl);
-            r.nccl = nullptr;
-        }
+    abort_communicators(m);
     return mfail(m, NBODY_ERR_DEVICE, "timed out after " + std::to_string((int)waited) +
                                           " s waiting for the step (a peer rank is gone or stuck); the RCCL "
                                           "communicators were aborted");
@@ -525,6 +618,108 @@ extern "C" int nbody_multi_set_timeout(nbody_multi *m, double seconds)
     return NBODY_OK;
 }
 
+// ---- measurement: where a rank's step goes besides its kernels ---------------------------------------------------------
+// With timing on, the exchanges are bracketed by events on the streams they run on or are waited for on (Span kinds above);
+// the totals are sums of event-pair durations, read and reset by nbody_multi_timing_read.  Finished pairs are folded into
+// the totals as the list grows, so a long run holds a bounded number of events.
+
+static void fold_spans(Rank &r, bool wait)
+{
+    size_t done = 0;
+    for (; done < r.spans.size(); ++done) {
+        Rank::Span &sp = r.spans[done];
+        if (wait)
+            (void)hipEventSynchronize(sp.b);
+        else if (hipEventQuery(sp.b) != hipSuccess)
+            break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) {
+            r.span_ms[sp.kind] += t;
+            ++r.span_count[sp.kind];
+        }
+        r.ev_pool.push_back(sp.a);
+        r.ev_pool.push_back(sp.b);
+    }
+    r.spans.erase(r.spans.begin(), r.spans.begin() + (ptrdiff_t)done);
+}
+
+static hipEvent_t timing_event(Rank &r)
+{
+    hipEvent_t e = nullptr;
+    if (!r.ev_pool.empty()) {
+        e = r.ev_pool.back();
+        r.ev_pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+    }
+    return e;
+}
+
+// Records the start of a span on `stream` (the device must be current); nullptr when timing is off.
+static hipEvent_t span_begin(nbody_multi *m, Rank &r, hipStream_t stream)
+{
+    if (!m->timing)
+        return nullptr;
+    if (r.spans.size() >= 64)
+        fold_spans(r, false);
+    hipEvent_t a = timing_event(r);
+    if (a)
+        (void)hipEventRecord(a, stream);
+    return a;
+}
+
+static void span_end(nbody_multi *m, Rank &r, hipEvent_t a, int kind, hipStream_t stream)
+{
+    if (!a)
+        return;
+    hipEvent_t b = timing_event(r);
+    if (!b) {
+        r.ev_pool.push_back(a);
+        return;
+    }
+    (void)hipEventRecord(b, stream);
+    r.spans.push_back({a, b, kind});
+}
+
+extern "C" int nbody_multi_timing_enable(nbody_multi *m, int on)
+{
+    if (!m)
+        return NBODY_ERR_INVALID;
+    m->timing = on != 0;
+    for (Rank &r : m->ranks)
+        if (r.ctx)
+            (void)nbody_timing_enable(r.ctx, on);
+    return NBODY_OK;
+}
+
+extern "C" int nbody_multi_timing_read(nbody_multi *m, int local_index, double *out16)
+{
+    if (!m || !out16 || local_index < 0 || local_index >= (int)m->ranks.size())
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_timing_read: bad argument");
+    Rank &r = m->ranks[(size_t)local_index];
+    MHIP(m, hipSetDevice(r.device));
+    fold_spans(r, true);
+    double k[6] = {0, 0, 0, 0, 0, 0};
+    MCTX(m, r, nbody_timing_read_ex(r.ctx, k));
+    out16[0] = (double)r.steps;
+    out16[1] = r.host_ms;
+    out16[2] = k[0];  // force kernels: sum of launch durations
+    out16[3] = k[1];
+    out16[4] = k[2];  // what runs behind the force pass (summation, update, kicks)
+    out16[5] = k[3];
+    out16[6] = k[4];  // auxiliary stream (diagonal tiles)
+    out16[7] = k[5];
+    for (int i = 0; i < 4; ++i) {
+        out16[8 + 2 * i] = r.span_ms[i];
+        out16[9 + 2 * i] = (double)r.span_count[i];
+        r.span_ms[i] = 0;
+        r.span_count[i] = 0;
+    }
+    r.steps = 0;
+    r.host_ms = 0;
+    return NBODY_OK;
+}
+
 // ---- the exchanges -------------------------------------------------------------------------------------------------
 
 typedef float *Rank::*RankBuffer;
@@ -534,6 +729,7 @@ typedef float *Rank::*RankBuffer;
 static int start_allgather(nbody_multi *m, Channel &ch, RankBuffer buf, size_t slice_floats)
 {
     const size_t nl = m->ranks.size();
+    std::vector<hipEvent_t> began(nl, nullptr);
     for (size_t i = 0; i < nl; ++i) {
         Rank &r = m->ranks[i];
         MHIP(m, hipSetDevice(r.device));
@@ -548,6 +744,7 @@ static int start_allgather(nbody_multi *m, Channel &ch, RankBuffer buf, size_t s
             for (size_t j = 0; j < nl; ++j)
                 MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[j], 0));
         }
+        began[i] = span_begin(m, r, r.comm);
     }
     if (rccl(m)) {
         MNCCL(m, ncclGroupStart());
@@ -574,11 +771,14 @@ static int start_allgather(nbody_multi *m, Channel &ch, RankBuffer buf, size_t s
         Rank &r = m->ranks[i];
         MHIP(m, hipSetDevice(r.device));
         MHIP(m, hipEventRecord(ch.done[i], r.comm));
+        span_end(m, r, began[i], kSpanPosComm, r.comm);
     }
     return NBODY_OK;
 }
 
-// Orders `stream` of local rank i behind the arrival of every other rank's slice.
+// Orders `stream` of local rank i behind the arrival of every other rank's slice -- and behind the departure of its own:
+// the consumer is also the next writer of the rank's slice (update, kick-drift, the next column-side sums), and a peer copy
+// that is still reading it runs on the rank's OWN communication stream (RCCL: done[i] marks the whole collective).
 static int wait_allgather(nbody_multi *m, Channel &ch, size_t i, hipStream_t stream)
 {
     Rank &r = m->ranks[i];
@@ -587,8 +787,7 @@ static int wait_allgather(nbody_multi *m, Channel &ch, size_t i, hipStream_t str
         MHIP(m, hipStreamWaitEvent(stream, ch.done[i], 0));
     } else {
         for (size_t j = 0; j < m->ranks.size(); ++j)
-            if (j != i)
-                MHIP(m, hipStreamWaitEvent(stream, ch.done[j], 0));
+            MHIP(m, hipStreamWaitEvent(stream, ch.done[j], 0));
     }
     return NBODY_OK;
 }
@@ -600,6 +799,7 @@ static int start_ring(nbody_multi *m)
     const size_t nl = m->ranks.size();
     const int P = m->world;
     const size_t chunk_floats = 4 * (size_t)m->chunk;
+    std::vector<hipEvent_t> began(nl, nullptr);
     for (size_t i = 0; i < nl; ++i) {
         Rank &r = m->ranks[i];
         MHIP(m, hipSetDevice(r.device));
@@ -614,6 +814,7 @@ static int start_ring(nbody_multi *m)
             for (size_t j = 0; j < nl; ++j)
                 MHIP(m, hipStreamWaitEvent(r.comm, m->ch_pos.ready[j], 0));
         }
+        began[i] = span_begin(m, r, r.comm);
     }
     for (int h = 1; h < P; ++h) {
         if (rccl(m)) {
@@ -655,6 +856,7 @@ static int start_ring(nbody_multi *m)
         Rank &r = m->ranks[i];
         MHIP(m, hipSetDevice(r.device));
         MHIP(m, hipEventRecord(m->ch_pos.done[i], r.comm));
+        span_end(m, r, began[i], kSpanPosComm, r.comm);
     }
     return NBODY_OK;
 }
@@ -705,11 +907,19 @@ static int forces_all_columns(nbody_multi *m, float softening)
                 Rank &r = m->ranks[i];
                 int recv_c = 0;
                 nbody_multi_ring_schedule(r.rank, P, h, nullptr, &recv_c);
+                MHIP(m, hipSetDevice(r.device));
+                hipEvent_t t0 = span_begin(m, r, r.compute);
                 int rc = wait_ring_hop(m, i, h, r.compute);
                 if (rc != NBODY_OK)
                     return rc;
+                span_end(m, r, t0, kSpanPosWait, r.compute);
                 MCTX(m, r, nbody_forces(r.ctx, r.pos, (int64_t)recv_c * m->chunk, m->chunk, softening));
             }
+        // the next writer of the rank's own rows (the update behind these launches) follows the rank's own sends as well
+        for (size_t i = 0; i < nl; ++i) {
+            MHIP(m, hipSetDevice(m->ranks[i].device));
+            MHIP(m, hipStreamWaitEvent(m->ranks[i].compute, m->ch_pos.done[i], 0));
+        }
         m->exchange_in_flight = false;
         return NBODY_OK;
     }
@@ -719,9 +929,11 @@ static int forces_all_columns(nbody_multi *m, float softening)
         MHIP(m, hipSetDevice(r.device));
         MHIP(m, hipStreamWaitEvent(r.side, r.ev_start, 0));
         if (m->exchange_in_flight) {
+            hipEvent_t t0 = span_begin(m, r, r.side);  // fires when the previous update is over: the launch could start here
             int rc = wait_allgather(m, m->ch_pos, i, r.side);
             if (rc != NBODY_OK)
                 return rc;
+            span_end(m, r, t0, kSpanPosWait, r.side);
         }
         // all other chunks in one launch on the second stream: its workgroups fill the CUs the first launch's tail leaves idle
         MCTX(m, r, nbody_set_stream(r.ctx, r.side));
@@ -804,18 +1016,44 @@ static int sum_forces(nbody_multi *m)
 {
     if (!pair_once(m) || m->world == 1)
         return NBODY_OK;  // one context: nbody_update / nbody_kdk_* run the reduction themselves
-    for (Rank &r : m->ranks)
+    std::vector<hipEvent_t> began(m->ranks.size(), nullptr);
+    for (size_t i = 0; i < m->ranks.size(); ++i) {
+        Rank &r = m->ranks[i];
         MCTX(m, r, nbody_sym_reduce(r.ctx));
+        MHIP(m, hipSetDevice(r.device));
+        began[i] = span_begin(m, r, r.compute);
+    }
     int rc = exchange_column_sums(m);
-    for (size_t i = 0; rc == NBODY_OK && i < m->ranks.size(); ++i)
+    for (size_t i = 0; rc == NBODY_OK && i < m->ranks.size(); ++i) {
         rc = wait_allgather(m, m->ch_col, i, m->ranks[i].compute);
+        span_end(m, m->ranks[i], began[i], kSpanColumns, m->ranks[i].compute);
+    }
     return rc;
 }
 
+static int step_enqueue(nbody_multi *m, float dt, float softening);
+
 static int step_async(nbody_multi *m, float dt, float softening)
 {
+    if (m->failed)
+        return mfail(m, NBODY_ERR_DEVICE, "nbody_multi_step: an earlier exchange failed and the communicators were aborted (" +
+                                              m->err + ")");
     if (!m->have_state && m->n_padded)
         return mfail(m, NBODY_ERR_STATE, "nbody_multi_step: call nbody_multi_set_state first");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = step_enqueue(m, dt, softening);
+    if (m->timing) {
+        const double ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (Rank &r : m->ranks) {
+            r.host_ms += ms / (double)m->ranks.size();  // the host thread enqueues the local ranks one after the other
+            ++r.steps;
+        }
+    }
+    return rc;
+}
+
+static int step_enqueue(nbody_multi *m, float dt, float softening)
+{
     int rc;
     if (m->cfg.integrator == NBODY_INTEGRATOR_KDK) {
         // velocity Verlet: the drifted rows are exchanged BEFORE the forces; the own-chunk launch still runs beside the exchange
@@ -912,47 +1150,269 @@ extern "C" int nbody_multi_step_n(nbody_multi *m, int k, float dt, float softeni
 }
 
 // ---- state in and out ------------------------------------------------------------------------------------------------
+// NBODY_ORDER_MORTON: the replicas hold the bodies in nbody_morton_order of the positions; Rank::order_dev says, on every
+// rank's own device, which of the caller's bodies sits in slot k.  The layout is laid and refreshed ON THE DEVICE
+// (csrc/nbody_order.hip): every rank sorts its own replica and gets the same permutation, the velocity rows are re-dealt
+// through one gather of all rows, and the host sees the order only when it asks for it (download, nbody_multi_order).
 
 static int upload_softening(nbody_multi *m);
 
-extern "C" int nbody_multi_set_state(nbody_multi *m, const float *host_pos, const float *host_vel)
+// The host copy of the order, fetched when it is stale.
+static int host_order(nbody_multi *m)
+{
+    if (m->cfg.body_order != NBODY_ORDER_MORTON || !m->n_bodies) {
+        m->order.clear();
+        return NBODY_OK;
+    }
+    if (m->order_host_valid)
+        return NBODY_OK;
+    Rank &r0 = m->ranks[0];
+    m->order.resize((size_t)m->n_bodies);
+    MHIP(m, hipSetDevice(r0.device));
+    MHIP(m, hipStreamSynchronize(r0.compute));
+    MHIP(m, hipMemcpy(m->order.data(), r0.order_dev, sizeof(int64_t) * (size_t)m->n_bodies, hipMemcpyDeviceToHost));
+    m->order_host_valid = true;
+    return NBODY_OK;
+}
+
+// Every rank's velocity rows into every local rank's vel_all, on the communication streams; the compute streams are ordered
+// behind the arrival.  The state must be settled (nothing in flight writes a velocity).
+static int gather_all_velocities(nbody_multi *m)
+{
+    const size_t nl = m->ranks.size(), chunk_floats = 4 * (size_t)m->chunk;
+    for (Rank &r : m->ranks) {
+        MHIP(m, hipSetDevice(r.device));
+        if (!r.vel_all)
+            MHIP(m, hipMalloc((void **)&r.vel_all, sizeof(float) * 4 * (size_t)m->n_padded));
+    }
+    if (rccl(m)) {
+        MNCCL(m, ncclGroupStart());
+        for (Rank &r : m->ranks) {
+            ncclResult_t q = ncclAllGather(r.vel, r.vel_all, chunk_floats, ncclFloat, r.nccl, r.comm);
+            if (q != ncclSuccess) {
+                (void)ncclGroupEnd();
+                return mfail(m, NBODY_ERR_DEVICE, std::string("ncclAllGather: RCCL: ") + ncclGetErrorString(q));
+            }
+        }
+        MNCCL(m, ncclGroupEnd());
+    } else {
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            for (Rank &d : m->ranks)
+                MHIP(m, hipMemcpyPeerAsync(d.vel_all + (size_t)r.rank * chunk_floats, d.device, r.vel, r.device,
+                                           chunk_floats * sizeof(float), r.comm));
+        }
+    }
+    for (Rank &r : m->ranks) {
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipEventRecord(r.ev_vel, r.comm));
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        if (rccl(m)) {
+            MHIP(m, hipStreamWaitEvent(r.compute, r.ev_vel, 0));
+        } else {
+            for (size_t j = 0; j < nl; ++j)
+                MHIP(m, hipStreamWaitEvent(r.compute, m->ranks[j].ev_vel, 0));
+        }
+    }
+    return NBODY_OK;
+}
+
+// Applies the permutation every local rank's context holds (nbody_order_compute / nbody_order_set: the same on every rank)
+// to the whole state: the replica in place, the rank's velocity rows out of a gather of all rows, the rank's softening
+// copy, and the order array (composed).  The state must be settled.  Asynchronous on the compute streams.
+static int apply_order(nbody_multi *m)
+{
+    const int64_t n = m->n_bodies;
+    for (Rank &r : m->ranks) {
+        MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+        MCTX(m, r, nbody_order_gather(r.ctx, r.pos, r.pos, 0, n, 4));
+    }
+    if (m->world == 1) {
+        Rank &r = m->ranks[0];
+        MCTX(m, r, nbody_order_gather(r.ctx, r.vel, r.vel, 0, n, 4));
+    } else {
+        int rc = gather_all_velocities(m);
+        if (rc != NBODY_OK)
+            return rc;
+        for (Rank &r : m->ranks)  // beyond n the permutation is the identity: the padding rows copy themselves
+            MCTX(m, r, nbody_order_gather(r.ctx, r.vel, r.vel_all, (int64_t)r.rank * m->chunk, m->chunk, 4));
+    }
+    for (Rank &r : m->ranks) {
+        MCTX(m, r, nbody_order_permute_softening(r.ctx));
+        if (r.order_dev)
+            MCTX(m, r, nbody_order_gather(r.ctx, r.order_dev, r.order_dev, 0, n, 2));
+        MCTX(m, r, nbody_invalidate_forces(r.ctx));
+    }
+    m->order_host_valid = false;
+    m->kdk_ready = false;
+    m->exchange_in_flight = false;
+    return NBODY_OK;
+}
+
+// A new curve through the positions the replicas hold now.
+static int reorder_device(nbody_multi *m)
+{
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    std::vector<hipEvent_t> began(m->ranks.size(), nullptr);
+    for (size_t i = 0; i < m->ranks.size(); ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        began[i] = span_begin(m, r, r.compute);
+        MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+        MCTX(m, r, nbody_order_compute(r.ctx, r.pos, m->n_bodies, r.order_dev));  // ties follow the caller's indices
+    }
+    rc = apply_order(m);
+    for (size_t i = 0; rc == NBODY_OK && i < m->ranks.size(); ++i) {
+        Rank &r = m->ranks[i];
+        MHIP(m, hipSetDevice(r.device));
+        span_end(m, r, began[i], kSpanReorder, r.compute);
+    }
+    m->steps_since_order = 0;
+    return rc;
+}
+
+static bool morton(const nbody_multi *m) { return m->cfg.body_order == NBODY_ORDER_MORTON && m->n_bodies > 0; }
+
+// Host rows of n_bodies float4 (the caller's order) into a padded staging vector: the padding = zero-mass bodies at the
+// origin, the reference's own device (kernel.cu:265-277): they add exactly 0.
+static void pad_rows(const nbody_multi *m, const float *host, std::vector<float> &out)
+{
+    out.assign(4 * (size_t)m->n_padded, 0.f);
+    if (m->n_bodies)
+        std::memcpy(out.data(), host, sizeof(float) * 4 * (size_t)m->n_bodies);
+}
+
+static int upload_positions(nbody_multi *m, const std::vector<float> &pos)
+{
+    for (Rank &r : m->ranks) {
+        if (!m->n_padded)
+            break;
+        MHIP(m, hipSetDevice(r.device));
+        MHIP(m, hipMemcpyAsync(r.pos, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice, r.compute));
+        MHIP(m, hipStreamSynchronize(r.compute));
+        MCTX(m, r, nbody_invalidate_forces(r.ctx));
+    }
+    return NBODY_OK;
+}
+
+static int set_state_impl(nbody_multi *m, const float *host_pos, const float *host_vel)
 {
     if (!m || ((!host_pos || !host_vel) && m->n_bodies))
         return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_state: NULL argument");
     int rc = settle(m);
     if (rc != NBODY_OK)
         return rc;
-    // padding = zero-mass bodies at the origin, the reference's own device (kernel.cu:265-277): they add exactly 0
-    std::vector<float> pos(4 * (size_t)m->n_padded, 0.f), vel(4 * (size_t)m->n_padded, 0.f);
-    m->order.clear();
-    if (m->n_bodies && m->cfg.body_order == NBODY_ORDER_MORTON) {  // slot k <- the caller's body order[k]; padding stays behind
-        m->order.resize((size_t)m->n_bodies);
-        if (nbody_morton_order(host_pos, m->n_bodies, m->order.data()) != NBODY_OK)
-            return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_state: nbody_morton_order failed");
-        for (int64_t k = 0; k < m->n_bodies; ++k) {
-            std::memcpy(&pos[4 * (size_t)k], host_pos + 4 * (size_t)m->order[(size_t)k], sizeof(float) * 4);
-            std::memcpy(&vel[4 * (size_t)k], host_vel + 4 * (size_t)m->order[(size_t)k], sizeof(float) * 4);
-        }
-    } else if (m->n_bodies) {
-        std::memcpy(pos.data(), host_pos, sizeof(float) * 4 * (size_t)m->n_bodies);
-        std::memcpy(vel.data(), host_vel, sizeof(float) * 4 * (size_t)m->n_bodies);
-    }
+    std::vector<float> pos, vel;
+    pad_rows(m, host_pos, pos);
+    pad_rows(m, host_vel, vel);
+    rc = upload_positions(m, pos);
+    if (rc != NBODY_OK)
+        return rc;
     for (Rank &r : m->ranks) {
         if (!m->n_padded)
             break;
         MHIP(m, hipSetDevice(r.device));
-        MHIP(m, hipMemcpyAsync(r.pos, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice, r.compute));
         MHIP(m, hipMemcpyAsync(r.vel, vel.data() + 4 * (size_t)r.rank * (size_t)m->chunk, sizeof(float) * 4 * (size_t)m->chunk,
                                hipMemcpyHostToDevice, r.compute));
         MHIP(m, hipStreamSynchronize(r.compute));
-        MCTX(m, r, nbody_invalidate_forces(r.ctx));
+        if (r.order_dev) {
+            MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+            MCTX(m, r, nbody_order_identity(r.ctx, r.order_dev, m->n_bodies));
+        }
+    }
+    m->order_host_valid = false;
+    m->kdk_ready = false;
+    m->have_state = true;
+    m->steps_since_order = 0;
+    if (m->eps_on)
+        rc = upload_softening(m);  // the caller's order, like the state just uploaded
+    if (rc == NBODY_OK && morton(m))
+        rc = reorder_device(m);    // the curve through these positions; velocities and softening lengths follow their bodies
+    return rc;
+}
+
+extern "C" int nbody_multi_set_state(nbody_multi *m, const float *host_pos, const float *host_vel)
+{
+    return guarded(m, [&] { return set_state_impl(m, host_pos, host_vel); });
+}
+
+// setParticlesPosition / setParticlesVelocity (kernel.cu:163-188) are independent copies in the reference: so are these.
+// New positions keep every body's velocity and softening length (NBODY_ORDER_MORTON: each body's new position goes to the
+// slot the body is in, then the new curve is laid through them); new velocities leave the positions alone.
+static int set_positions_impl(nbody_multi *m, const float *host_pos)
+{
+    if (!m || (!host_pos && m->n_bodies))
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_positions: NULL argument");
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    std::vector<float> pos;
+    pad_rows(m, host_pos, pos);
+    if (morton(m) && m->have_state) {  // body order[k] of the new positions into slot k, where its velocity already is
+        for (Rank &r : m->ranks) {
+            MHIP(m, hipSetDevice(r.device));
+            if (!r.vel_all)
+                MHIP(m, hipMalloc((void **)&r.vel_all, sizeof(float) * 4 * (size_t)m->n_padded));
+            MHIP(m, hipMemcpyAsync(r.vel_all, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice, r.compute));
+            MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+            MCTX(m, r, nbody_order_set(r.ctx, r.order_dev, m->n_bodies, 0));
+            MCTX(m, r, nbody_order_gather(r.ctx, r.pos, r.vel_all, 0, m->n_bodies, 4));
+            MHIP(m, hipStreamSynchronize(r.compute));
+            MCTX(m, r, nbody_invalidate_forces(r.ctx));
+        }
+    } else {
+        rc = upload_positions(m, pos);
     }
     m->kdk_ready = false;
     m->have_state = true;
     m->steps_since_order = 0;
-    if (m->eps_on && m->cfg.body_order == NBODY_ORDER_MORTON)
-        return upload_softening(m);  // the lengths follow their bodies to the new slots
+    if (rc == NBODY_OK && morton(m))
+        rc = reorder_device(m);
+    return rc;
+}
+
+static int set_velocities_impl(nbody_multi *m, const float *host_vel)
+{
+    if (!m || (!host_vel && m->n_bodies))
+        return mfail(m, NBODY_ERR_INVALID, "nbody_multi_set_velocities: NULL argument");
+    int rc = settle(m);
+    if (rc != NBODY_OK)
+        return rc;
+    std::vector<float> vel;
+    pad_rows(m, host_vel, vel);
+    for (Rank &r : m->ranks) {
+        if (!m->n_padded)
+            break;
+        MHIP(m, hipSetDevice(r.device));
+        const size_t lo = (size_t)r.rank * (size_t)m->chunk;
+        if (morton(m)) {  // all rows in the caller's order, then this rank's rows through the order array
+            if (!r.vel_all)
+                MHIP(m, hipMalloc((void **)&r.vel_all, sizeof(float) * 4 * (size_t)m->n_padded));
+            MHIP(m, hipMemcpyAsync(r.vel_all, vel.data(), sizeof(float) * vel.size(), hipMemcpyHostToDevice, r.compute));
+            MCTX(m, r, nbody_set_stream(r.ctx, r.compute));
+            MCTX(m, r, nbody_order_set(r.ctx, r.order_dev, m->n_bodies, 0));
+            MCTX(m, r, nbody_order_gather(r.ctx, r.vel, r.vel_all, (int64_t)lo, m->chunk, 4));
+        } else {
+            MHIP(m, hipMemcpyAsync(r.vel, vel.data() + 4 * lo, sizeof(float) * 4 * (size_t)m->chunk, hipMemcpyHostToDevice, r.compute));
+        }
+        MHIP(m, hipStreamSynchronize(r.compute));
+    }
     return NBODY_OK;
+}
+
+extern "C" int nbody_multi_set_positions(nbody_multi *m, const float *host_pos)
+{
+    return guarded(m, [&] { return set_positions_impl(m, host_pos); });
+}
+
+extern "C" int nbody_multi_set_velocities(nbody_multi *m, const float *host_vel)
+{
+    return guarded(m, [&] { return set_velocities_impl(m, host_vel); });
 }
 
 static int upload_softening(nbody_multi *m)  // m->eps_caller (the caller's order, or empty) in the order of the replicas
@@ -961,10 +1421,10 @@ static int upload_softening(nbody_multi *m)  // m->eps_caller (the caller's orde
     const bool on = !m->eps_caller.empty() || (m->eps_on && m->n_bodies == 0);
     if (on) {
         eps.assign((size_t)m->n_padded, 0.f);
-        if (m->cfg.body_order == NBODY_ORDER_MORTON && m->n_bodies) {
-            if (m->order.size() != (size_t)m->n_bodies)
-                return mfail(m, NBODY_ERR_STATE, "nbody_multi_set_particle_softening: with NBODY_ORDER_MORTON call "
-                                                 "nbody_multi_set_state first (the order is a function of the positions)");
+        if (morton(m)) {
+            int rc = host_order(m);
+            if (rc != NBODY_OK)
+                return rc;
             for (int64_t k = 0; k < m->n_bodies; ++k)
                 eps[(size_t)k] = m->eps_caller[(size_t)m->order[(size_t)k]];
         } else if (m->n_bodies) {
@@ -981,15 +1441,17 @@ extern "C" int nbody_multi_set_particle_softening(nbody_multi *m, const float *h
 {
     if (!m)
         return NBODY_ERR_INVALID;
-    int rc = settle(m);
-    if (rc != NBODY_OK)
-        return rc;
-    m->eps_on = host_eps != nullptr;
-    if (host_eps)
-        m->eps_caller.assign(host_eps, host_eps + m->n_bodies);
-    else
-        m->eps_caller.clear();
-    return upload_softening(m);
+    return guarded(m, [&] {
+        int rc = settle(m);
+        if (rc != NBODY_OK)
+            return rc;
+        m->eps_on = host_eps != nullptr;
+        if (host_eps)
+            m->eps_caller.assign(host_eps, host_eps + m->n_bodies);
+        else
+            m->eps_caller.clear();
+        return upload_softening(m);
+    });
 }
 
 extern "C" int nbody_multi_set_reorder_period(nbody_multi *m, int64_t steps)
@@ -1004,17 +1466,11 @@ extern "C" int nbody_multi_reorder(nbody_multi *m)
 {
     if (!m)
         return NBODY_ERR_INVALID;
-    if (m->cfg.body_order != NBODY_ORDER_MORTON || !m->have_state || !m->n_bodies) {
+    if (!morton(m) || !m->have_state) {
         m->steps_since_order = 0;
         return NBODY_OK;  // nothing to refresh
     }
-    std::vector<float> pos(4 * (size_t)m->n_bodies), vel(4 * (size_t)m->n_bodies);
-    int rc = nbody_multi_download(m, pos.data(), vel.data());  // the caller's order; collective in the one-rank-per-process model
-    if (rc == NBODY_OK)
-        rc = nbody_multi_set_state(m, pos.data(), vel.data());  // a new curve through the current positions
-    if (rc == NBODY_OK && m->eps_on)
-        rc = upload_softening(m);
-    return rc;
+    return guarded(m, [&] { return reorder_device(m); });
 }
 
 static int download_device_order(nbody_multi *m, float *host_pos, float *host_vel);
@@ -1023,20 +1479,24 @@ extern "C" int nbody_multi_download(nbody_multi *m, float *host_pos, float *host
 {
     if (!m)
         return NBODY_ERR_INVALID;
-    if (m->order.empty())
-        return download_device_order(m, host_pos, host_vel);
-    // the replicas hold the bodies in nbody_morton_order: back to the caller's
-    std::vector<float> pos(host_pos ? 4 * (size_t)m->n_bodies : 0), vel(host_vel ? 4 * (size_t)m->n_bodies : 0);
-    int rc = download_device_order(m, host_pos ? pos.data() : nullptr, host_vel ? vel.data() : nullptr);
-    if (rc != NBODY_OK)
-        return rc;
-    for (int64_t k = 0; k < m->n_bodies; ++k) {
-        if (host_pos)
-            std::memcpy(host_pos + 4 * (size_t)m->order[(size_t)k], &pos[4 * (size_t)k], sizeof(float) * 4);
-        if (host_vel)
-            std::memcpy(host_vel + 4 * (size_t)m->order[(size_t)k], &vel[4 * (size_t)k], sizeof(float) * 4);
-    }
-    return NBODY_OK;
+    return guarded(m, [&] {
+        if (!morton(m))
+            return download_device_order(m, host_pos, host_vel);
+        // the replicas hold the bodies in nbody_morton_order: back to the caller's
+        std::vector<float> pos(host_pos ? 4 * (size_t)m->n_bodies : 0), vel(host_vel ? 4 * (size_t)m->n_bodies : 0);
+        int rc = download_device_order(m, host_pos ? pos.data() : nullptr, host_vel ? vel.data() : nullptr);
+        if (rc == NBODY_OK)
+            rc = host_order(m);
+        if (rc != NBODY_OK)
+            return rc;
+        for (int64_t k = 0; k < m->n_bodies; ++k) {
+            if (host_pos)
+                std::memcpy(host_pos + 4 * (size_t)m->order[(size_t)k], &pos[4 * (size_t)k], sizeof(float) * 4);
+            if (host_vel)
+                std::memcpy(host_vel + 4 * (size_t)m->order[(size_t)k], &vel[4 * (size_t)k], sizeof(float) * 4);
+        }
+        return (int)NBODY_OK;
+    });
 }
 
 extern "C" int nbody_multi_order(nbody_multi *m, int64_t *perm)
@@ -1045,9 +1505,16 @@ extern "C" int nbody_multi_order(nbody_multi *m, int64_t *perm)
         return NBODY_ERR_INVALID;
     if (!m->have_state && m->n_bodies)
         return mfail(m, NBODY_ERR_STATE, "nbody_multi_order: no state was ever set");
-    for (int64_t k = 0; k < m->n_bodies; ++k)
-        perm[k] = m->order.empty() ? k : m->order[(size_t)k];
-    return NBODY_OK;
+    return guarded(m, [&] {
+        int rc = settle(m);
+        if (rc == NBODY_OK)
+            rc = host_order(m);
+        if (rc != NBODY_OK)
+            return rc;
+        for (int64_t k = 0; k < m->n_bodies; ++k)
+            perm[k] = m->order.empty() ? k : m->order[(size_t)k];
+        return (int)NBODY_OK;
+    });
 }
 
 static int download_device_order(nbody_multi *m, float *host_pos, float *host_vel)
@@ -1063,7 +1530,6 @@ static int download_device_order(nbody_multi *m, float *host_pos, float *host_ve
         MHIP(m, hipMemcpy(host_pos, r0.pos, sizeof(float) * 4 * (size_t)m->n_bodies, hipMemcpyDeviceToHost));
     if (!host_vel)
         return NBODY_OK;
-    const size_t chunk_floats = 4 * (size_t)m->chunk;
     auto copy_rows = [&](const float *dev_rows, int rank) -> hipError_t {  // the real bodies among this rank's rows
         const int64_t lo = (int64_t)rank * m->chunk, hi = std::min(lo + m->chunk, m->n_bodies);
         if (hi <= lo)
@@ -1077,13 +1543,13 @@ static int download_device_order(nbody_multi *m, float *host_pos, float *host_ve
         }
         return NBODY_OK;
     }
-    if (!m->gather_vel)
-        MHIP(m, hipMalloc((void **)&m->gather_vel, sizeof(float) * 4 * (size_t)m->n_padded));
-    MNCCL(m, ncclAllGather(r0.vel, m->gather_vel, chunk_floats, ncclFloat, r0.nccl, r0.comm));
-    rc = wait_all(m);
+    rc = gather_all_velocities(m);  // collective: every process downloads
+    if (rc == NBODY_OK)
+        rc = wait_all(m);
     if (rc != NBODY_OK)
         return rc;
-    MHIP(m, hipMemcpy(host_vel, m->gather_vel, sizeof(float) * 4 * (size_t)m->n_bodies, hipMemcpyDeviceToHost));
+    MHIP(m, hipSetDevice(r0.device));
+    MHIP(m, hipMemcpy(host_vel, r0.vel_all, sizeof(float) * 4 * (size_t)m->n_bodies, hipMemcpyDeviceToHost));
     return NBODY_OK;
 }
 

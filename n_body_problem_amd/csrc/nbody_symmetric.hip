@@ -29,6 +29,7 @@
 // operations per 64 x 4 pairs) against 2 x (12 + 1) for the two ordered interactions it replaces.
 #include "nbody_kernels.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -412,7 +413,10 @@ __device__ __forceinline__ int sym_group(int g, int wave, int spacing, int G)
 // ---- off-diagonal tiles (I < J) ------------------------------------------------------------------------------
 typedef float nb_f16 __attribute__((ext_vector_type(16)));
 template <int W, bool GUARD, bool ROWS8 = false>  // ROWS8: equal-mass tiles through the eight-rows-per-lane loop (<= 128 VGPRs)
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? 4 : 5))) void force_sym_kernel(SymArgs a)  // <= 96 VGPRs
+#ifndef NB_S8_WAVES
+#define NB_S8_WAVES 4  /* waves per SIMD the eight-row kernel is allocated for (A/B: 3 leaves 168 VGPRs) */
+#endif
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ? NB_S8_WAVES : 5))) void force_sym_kernel(SymArgs a)  // <= 96 VGPRs
 {
     constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -890,9 +894,17 @@ static hipError_t sym_launch(K kernel, int blocks, int waves, size_t lds, const 
     return hipGetLastError();
 }
 
+// NBODY_SYM_LDS_PAD (bytes, experiments only): unused LDS per workgroup, to lower the number of workgroups a CU holds
+static size_t sym_lds_pad()
+{
+    static const size_t pad = getenv("NBODY_SYM_LDS_PAD") ? (size_t)atol(getenv("NBODY_SYM_LDS_PAD")) : 0;
+    return pad;
+}
+
 static size_t sym_lds_bytes_for(int waves, int split_len)
 {
-    return (size_t)waves * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + (size_t)waves * 64 * sizeof(float);
+    return (size_t)waves * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + (size_t)waves * 64 * sizeof(float) +
+           sym_lds_pad();
 }
 
 template <int W>

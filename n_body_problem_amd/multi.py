@@ -26,7 +26,7 @@ from . import _lib
 from . import system as _system
 from ._lib import NBodyError
 
-FORCE_MODES = {"one_sided": 0, "pair_once": 1, "symmetric": 1}
+FORCE_MODES = {"one_sided": 0, "pair_once": 1, "symmetric": 1, "auto": 2}
 INTEGRATORS = {"kick_drift": 0, "kdk": 1}
 EXCHANGES = {"allgather": 0, "ring": 1}
 TRANSPORTS = {"rccl": 0, "peer_copy": 1}
@@ -101,9 +101,9 @@ class MultiGpuSystem:
         info = self.info()
         self.n_padded, self.chunk, self.split_len = info["n_padded"], info["rows_per_rank"], info["split_len"]
         self.world_size, self.local_ranks = info["world_size"], info["local_ranks"]
-        self._pos = np.zeros((self.num_bodies, 4), dtype=np.float32)
-        self._vel = np.zeros((self.num_bodies, 4), dtype=np.float32)
         self.kernels = self.shard(0)
+        if force_mode == "auto":   # the library chose (NBODY_FORCE_AUTO): ask the shard context
+            self.force_mode = {0: "one_sided", 1: "pair_once"}[int(self._lib.nbody_force_mode(self.kernels._ctx))]
 
     @classmethod
     def from_torch_distributed(cls, num_bodies: int, device: int, group=None, **kw) -> "MultiGpuSystem":
@@ -179,13 +179,27 @@ class MultiGpuSystem:
     def set_timeout(self, seconds: float) -> None:
         _check(self._lib.nbody_multi_set_timeout(self._m, float(seconds)), self._m)
 
-    # -- buffers (kernel.cu:163-188) -----------------------------------------------------------------
-    def _upload(self) -> None:
-        _check(self._lib.nbody_multi_set_state(self._m, self._pos.ctypes.data_as(ctypes.c_void_p),
-                                               self._vel.ctypes.data_as(ctypes.c_void_p)), self._m)
+    def timing(self, on: bool = True) -> None:
+        """Bracket the exchanges with HIP events and let the shard contexts time their kernels (``nbody_multi_timing_*``)."""
+        _check(self._lib.nbody_multi_timing_enable(self._m, 1 if on else 0), self._m)
 
+    def read_timing(self, local_index: int = 0) -> dict:
+        """Totals of local rank ``local_index`` since the last read (sums of event-pair durations in ms, and counts): the
+        kernels of its shard context, the position exchange on the communication stream and as the waiting force launch
+        saw it, the pair-once column-sum exchange, layout refreshes, and the host time spent enqueuing the steps."""
+        out = (ctypes.c_double * 16)()
+        _check(self._lib.nbody_multi_timing_read(self._m, int(local_index), out), self._m)
+        keys = ("steps", "host_enqueue_ms", "force_ms", "force_launches", "update_ms", "update_launches", "aux_ms", "aux_launches",
+                "pos_exchange_comm_ms", "pos_exchanges", "pos_exchange_wait_ms", "pos_exchange_waits",
+                "column_sum_exchange_ms", "column_sum_exchanges", "reorder_ms", "reorders")
+        ints = {"steps", "force_launches", "update_launches", "aux_launches", "pos_exchanges", "pos_exchange_waits",
+                "column_sum_exchanges", "reorders"}
+        return {k: (int(v) if k in ints else float(v)) for k, v in zip(keys, out)}
+
+    # -- buffers (kernel.cu:163-188) -----------------------------------------------------------------
     def reorder(self) -> None:
-        """``body_order="morton"``: a new curve through the current positions (the layout decays as the bodies move)."""
+        """``body_order="morton"``: a new curve through the current positions (the layout decays as the bodies move); on the
+        device, every rank from its own replica."""
         _check(self._lib.nbody_multi_reorder(self._m), self._m)
 
     def set_reorder_period(self, steps: int) -> None:
@@ -209,18 +223,21 @@ class MultiGpuSystem:
         return a
 
     def setParticlesPosition(self, data) -> None:
-        """Host ``float4 {x,y,z,mass}`` of ALL bodies (the same on every process)."""
-        self._pos = self._rows(data).copy()
-        self._upload()
+        """Host ``float4 {x,y,z,mass}`` of ALL bodies (the same on every process).  An independent copy, as in the reference:
+        the velocities on the device stay with their bodies (``nbody_multi_set_positions``)."""
+        a = self._rows(data)
+        _check(self._lib.nbody_multi_set_positions(self._m, a.ctypes.data_as(ctypes.c_void_p)), self._m)
 
     def setParticlesVelocity(self, data) -> None:
-        """Host ``float4 {vx,vy,vz,eps}`` of ALL bodies (each rank keeps its own rows)."""
-        self._vel = self._rows(data).copy()
-        self._upload()
+        """Host ``float4 {vx,vy,vz,eps}`` of ALL bodies (each rank keeps its own rows); the positions on the device are not
+        touched (``nbody_multi_set_velocities``)."""
+        a = self._rows(data)
+        _check(self._lib.nbody_multi_set_velocities(self._m, a.ctypes.data_as(ctypes.c_void_p)), self._m)
 
     def set_state(self, positions, velocities) -> None:
-        self._pos, self._vel = self._rows(positions).copy(), self._rows(velocities).copy()
-        self._upload()
+        p, v = self._rows(positions), self._rows(velocities)
+        _check(self._lib.nbody_multi_set_state(self._m, p.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)),
+               self._m)
 
     set_particles_position = setParticlesPosition
     set_particles_velocity = setParticlesVelocity

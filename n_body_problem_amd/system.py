@@ -69,9 +69,11 @@ class NBodySystem:
 
     With the defaults it is the reference's single-GPU system: ``initialize(numBodies)``.
 
-    ``body_order="morton"`` (a context that owns every row): ``setParticlesPosition`` stores the bodies in
-    :func:`morton_order`, ``setParticlesVelocity`` follows, :meth:`download` undoes it; ``self.order[k]`` is the caller's index
-    of the body in slot ``k`` of the device tensors.  The physics is the same, the sums are taken in another order.
+    ``body_order="morton"`` (a context that owns every row): the device tensors hold the bodies in :func:`morton_order` of
+    their positions -- laid and refreshed ON THE DEVICE (``nbody_reorder``, csrc/nbody_order.hip: the same permutation as
+    the host function, without a host copy of the state) -- the setters and :meth:`download` speak the caller's order, and
+    ``self.order[k]`` is the caller's index of the body in slot ``k`` of the device tensors.  The physics is the same, the
+    sums are taken in another order.
     """
 
     def __init__(self, num_bodies: int, device: int = 0, row_lo: int = 0, row_count: Optional[int] = None,
@@ -79,7 +81,8 @@ class NBodySystem:
         if body_order not in BODY_ORDERS:
             raise ValueError(f"body_order must be one of {BODY_ORDERS}")
         self.body_order = body_order
-        self.order = None       # the permutation in use (set by setParticlesPosition)
+        self._order_dev = None   # body_order="morton": int64 device tensor, slot k holds the caller's body _order_dev[k]
+        self._order_host = None  # its host copy, fetched when asked for
         self._reorder_period, self._steps_since_order = 0, 0
         self._ctx = ctypes.c_void_p(None)
         self._lib = _lib.load()
@@ -102,6 +105,10 @@ class NBodySystem:
         # the reference's two device buffers: position "VBO" (all bodies) and velocities (own rows)
         self.positions = torch.zeros((self.num_bodies, 4), dtype=torch.float32, device=self.device)
         self.velocities = torch.zeros((self.row_count, 4), dtype=torch.float32, device=self.device)
+        if body_order == "morton":
+            self._order_dev = torch.empty((self.num_bodies,), dtype=torch.int64, device=self.device)
+            self._use_current_stream()
+            check(self._lib.nbody_order_identity(self._ctx, _ptr(self._order_dev), self.num_bodies), self._ctx)
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -126,18 +133,46 @@ class NBodySystem:
         s = torch.cuda.current_stream(self.device).cuda_stream
         check(self._lib.nbody_set_stream(self._ctx, ctypes.c_void_p(s)), self._ctx)
 
+    # -- body order ------------------------------------------------------------------------------
+    @property
+    def order(self):
+        """``order[k]`` = the caller's index of the body in slot ``k`` of the device tensors (``None``: stored as given)."""
+        if self._order_dev is None:
+            return None
+        if self._order_host is None:
+            self._order_host = self._order_dev.cpu().numpy()
+        return self._order_host
+
+    def _to_slots(self, dst, rows, floats_per_row: int) -> None:
+        """``dst[k] = rows[order[k]]`` on the device: ``rows`` (a device tensor in the caller's order) into the slots."""
+        self._use_current_stream()
+        check(self._lib.nbody_order_set(self._ctx, _ptr(self._order_dev), self.num_bodies, 0), self._ctx)
+        check(self._lib.nbody_order_gather(self._ctx, _ptr(dst), _ptr(rows), 0, self.num_bodies, floats_per_row), self._ctx)
+
+    def _lay_curve(self) -> None:
+        """``nbody_reorder``: positions, velocities, softening lengths and the order array into :func:`morton_order` of the
+        positions the device holds now."""
+        self._use_current_stream()
+        check(self._lib.nbody_reorder(self._ctx, _ptr(self.positions), _ptr(self.velocities), _ptr(self._eps_pp),
+                                      _ptr(self._order_dev), self.num_bodies), self._ctx)
+        self._order_host = None
+        self._steps_since_order = 0
+
     # -- buffers (kernel.cu:163-188) ----------------------------------------------------------
     def setParticlesPosition(self, data) -> None:
-        """Host ``float4 {x,y,z,mass}`` for ALL bodies -> the device position buffer."""
+        """Host ``float4 {x,y,z,mass}`` for ALL bodies -> the device position buffer.  An independent copy, as in the
+        reference: velocities and softening lengths already set stay with their bodies."""
         torch = _torch()
         a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
         if a.shape[0] != self.num_bodies:
             raise ValueError(f"expected {self.num_bodies} bodies, got {a.shape[0]}")
         if self.body_order == "morton":
-            self.order = morton_order(a)
-            a = np.ascontiguousarray(a[self.order])
-            self._steps_since_order = 0
-        self.positions.copy_(torch.from_numpy(a))
+            rows = torch.from_numpy(a).to(self.device)   # the caller's order; each body's position to the body's slot
+            self._to_slots(self.positions, rows, 4)
+            self._lay_curve()                            # then the curve through the new positions: everything follows
+            torch.cuda.current_stream(self.device).synchronize()   # `rows` is released behind the gather
+        else:
+            self.positions.copy_(torch.from_numpy(a))
         self._lib.nbody_invalidate_forces(self._ctx)
 
     def setParticlesVelocity(self, data) -> None:
@@ -151,10 +186,11 @@ class NBodySystem:
         if a.shape[0] != self.row_count:
             raise ValueError(f"expected {self.row_count} or {self.num_bodies} velocity rows, got {a.shape[0]}")
         if self.body_order == "morton":
-            if self.order is None:
-                raise NBodyError(_lib.NBODY_ERR_STATE, "body_order='morton': call setParticlesPosition before setParticlesVelocity")
-            a = a[self.order]
-        self.velocities.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+            rows = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            self._to_slots(self.velocities, rows, 4)
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            self.velocities.copy_(torch.from_numpy(np.ascontiguousarray(a)))
 
     set_particles_position = setParticlesPosition
     set_particles_velocity = setParticlesVelocity
@@ -168,27 +204,18 @@ class NBodySystem:
 
     def reorder(self) -> None:
         """``body_order="morton"``: a new curve through the current positions (the layout decays as the bodies move: at
-        N = 2^20 half of the gain is gone after ~300 steps of dt = 1e-3).  State to the host and back."""
+        N = 2^20 half of the gain is gone after ~300 steps of dt = 1e-3).  On the device (``nbody_reorder``), asynchronous."""
         self._steps_since_order = 0
-        if self.body_order != "morton" or self.order is None:
-            return
-        pos, vel = self.download()
-        eps = None
-        if self._eps_pp is not None:
-            e = self._eps_pp.cpu().numpy()
-            eps = np.empty_like(e)
-            eps[self.order] = e
-        self.setParticlesPosition(pos)
-        self.setParticlesVelocity(vel)
-        if eps is not None:
-            self.set_particle_softening(eps)
+        if self.body_order == "morton":
+            self._lay_curve()
 
     def download(self) -> Tuple[np.ndarray, np.ndarray]:
         """(positions, velocities) as host float32 arrays, in the caller's body order."""
         pos, vel = self.positions.cpu().numpy(), self.velocities.cpu().numpy()
-        if self.order is not None:
+        order = self.order
+        if order is not None:
             p, v = np.empty_like(pos), np.empty_like(vel)
-            p[self.order], v[self.order] = pos, vel
+            p[order], v[order] = pos, vel
             return p, v
         return pos, vel
 
@@ -203,8 +230,10 @@ class NBodySystem:
             self.reorder()
         self._steps_since_order += 1
         fn = self._lib.nbody_step if sync else self._lib.nbody_step_async
-        if masses is not None and self.order is not None:
-            masses = masses.reshape(-1)[_torch().from_numpy(self.order).to(self.device)].contiguous()
+        if masses is not None and self._order_dev is not None:   # the caller's order -> the slots
+            slots = _torch().empty_like(masses.reshape(-1))
+            self._to_slots(slots, masses.reshape(-1).contiguous(), 1)
+            masses = slots
         check(fn(self._ctx, _ptr(self.positions), _ptr(self.velocities), _ptr(masses), float(dt), float(softening)),
               self._ctx)
 
@@ -306,8 +335,11 @@ class NBodySystem:
         """``"one_sided"`` (default) or ``"symmetric"`` (the pair-once kernel; create the system with
         ``split_len=pair_once_split_len(n)``).  A shard in the pair-once mode exchanges ``self.colparts`` once per step:
         ``forces*`` -> ``sym_reduce()`` -> all-gather of ``sym_own_slice()`` -> ``update``."""
-        code = {"one_sided": 0, "symmetric": 1, "pair_once": 1}[mode]
+        code = {"one_sided": 0, "symmetric": 1, "pair_once": 1, "auto": 2}[mode]
         check(self._lib.nbody_set_force_mode(self._ctx, code), self._ctx)
+        self.split_len = int(self._lib.nbody_split_len(self._ctx))   # "auto" picks the split length of the mode it picks
+        self.force_mode = {0: "one_sided", 1: "pair_once"}[int(self._lib.nbody_force_mode(self._ctx))]
+        code = 1 if self.force_mode == "pair_once" else 0
         self.colparts = None
         if code == 1 and (self.row_lo != 0 or self.row_count != self.num_bodies):
             torch = _torch()  # the exchange buffer lives in a tensor so that torch.distributed can gather into it
@@ -340,8 +372,12 @@ class NBodySystem:
             t = t.to(device=self.device, dtype=torch.float32).contiguous()
             if t.numel() != self.num_bodies:
                 raise ValueError(f"expected {self.num_bodies} softening lengths, got {t.numel()}")
-            if self.order is not None:  # the caller's order -> the order of the device buffers
-                t = t.reshape(-1)[torch.from_numpy(self.order).to(self.device)].contiguous()
+            t = t.reshape(-1)
+            if self._order_dev is not None:  # the caller's order -> the order of the device buffers
+                slots = torch.empty_like(t)
+                self._to_slots(slots, t, 1)
+                torch.cuda.current_stream(self.device).synchronize()
+                t = slots
             self._eps_pp = t  # keeps the borrowed device buffer alive
         check(self._lib.nbody_set_particle_softening(self._ctx, _ptr(self._eps_pp)), self._ctx)
 
@@ -381,8 +417,10 @@ PAIR_ONCE_MIN_BODIES = 65536  # below it the pair-once grid is too coarse to fil
 def initialize(num_bodies: int, device: int = 0, force_mode: str = "one_sided", body_order: str = "given") -> NBodySystem:
     """``initialize(numBodies)`` of kernel.cu:130-161.  ``force_mode``: ``"one_sided"``, ``"pair_once"`` or ``"auto"``
     (pair-once from ``PAIR_ONCE_MIN_BODIES`` bodies on, where it is the faster one); ``body_order``: see :class:`NBodySystem`."""
-    if force_mode == "auto":
-        force_mode = "pair_once" if num_bodies >= PAIR_ONCE_MIN_BODIES else "one_sided"
+    if force_mode == "auto":   # nbody_set_force_mode(ctx, NBODY_FORCE_AUTO): the choice is the library's, for every host language
+        s = NBodySystem(num_bodies, device=device, body_order=body_order)
+        s.set_force_mode("auto")
+        return s
     s = NBodySystem(num_bodies, device=device, split_len=pair_once_split_len(num_bodies) if force_mode == "pair_once" else 0,
                     body_order=body_order)
     s.set_force_mode(force_mode)

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.nbody_abi_version() == 3           # 3: nbody_multi_config grew body_order
+    assert lib.nbody_abi_version() == 4           # 4: device-side body order, nbody_create_auto, NBODY_FORCE_AUTO, multi timing
     assert lib.nbody_status_string(0) == b"ok"
     for s in range(-5, 0):
         assert lib.nbody_status_string(s) not in (b"ok", b"unknown status")

@@ -295,3 +295,68 @@ def test_library_exchange_beside_torch_distributed_nccl(tmp_path):
     assert np.array_equal(g["order"], perm)
     sorted_p, sorted_v, _, _ = one_context(nb, pos[perm], vel[perm], int(g["n_padded"]), int(g["split_len"]), 3, "pair_once")
     assert np.array_equal(g["pm"][perm], sorted_p) and np.array_equal(g["vm"][perm], sorted_v)
+
+
+@pytest.mark.parametrize("exchange,force_mode", [("allgather", "pair_once"), ("ring", "one_sided")])
+def test_per_rank_breakdown_of_a_step(exchange, force_mode):
+    """nbody_multi_timing_*: where a rank's step goes besides its kernels -- what a one-shot 8-GPU run needs in its own
+    output to be diagnosed.  Timing changes no bit."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps, world = 40960, 4, 2
+    pos, vel = nb.plummer(n, seed=19)
+    out = {}
+    for timed in (True, False):
+        with MultiGpuSystem(n, devices=[0] * world, force_mode=force_mode, exchange=exchange, transport="peer_copy",
+                            body_order="morton") as m:
+            m.set_state(pos, vel)
+            m.step(DT, EPS)
+            if timed:
+                m.timing(True)
+                m.read_timing(0), m.read_timing(1)
+            m.step_n(steps, DT, EPS)
+            m.reorder()
+            if timed:
+                m.sync()
+                tms = [m.read_timing(i) for i in range(world)]
+                again = m.read_timing(0)
+            m.step_n(1, DT, EPS)
+            out[timed] = m.download()
+    assert np.array_equal(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])
+    for t in tms:
+        assert t["steps"] == steps and t["host_enqueue_ms"] > 0
+        assert t["force_ms"] > 0 and t["update_ms"] > 0
+        assert t["pos_exchanges"] == steps and t["pos_exchange_comm_ms"] > 0          # one exchange issued per step
+        hops = (world - 1) if exchange == "ring" else 1
+        assert t["pos_exchange_waits"] == steps * hops and t["pos_exchange_wait_ms"] > 0
+        assert t["column_sum_exchanges"] == (steps if force_mode == "pair_once" else 0)
+        assert t["reorders"] == 1 and 0 < t["reorder_ms"] < 50
+    assert again["steps"] == 0 and again["force_ms"] == 0 and again["pos_exchanges"] == 0   # a read resets the totals
+
+
+def test_bench_leaves_a_json_error_line_when_an_exchange_times_out():
+    """bench.py --exchange-timeout: a rank that waits longer than the timeout for an exchange prints ONE JSON line with
+    "error" and exits non-zero -- evidence instead of a kill at the driver's limit.  Rehearsed with two
+    peer-copy ranks on cuda:0 and a timeout shorter than a step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer_copy", "--single-device",
+           "--bodies", "262144", "--steps", "3", "--warmup", "1", "--exchange-timeout", "0.001", "--no-cpu-baseline",
+           "--no-extra-legs", "--no-sanity"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    lines = [json.loads(x) for x in res.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] is None and "timed out" in lines[0]["error"]
+    assert lines[0]["n_gpus"] == 2 and lines[0]["config"]["exchange_timeout_s"] == 0.001
+    # and with a sane timeout the same command measures, with the per-rank breakdown in its line
+    cmd[cmd.index("--exchange-timeout") + 1] = "60"
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([x for x in res.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "peer_copy" in line["config"]["backend"]
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1]
+    for r in line["per_rank"]:
+        assert r["force_ms"] > 0 and r["pos_exchange_wait_ms"] >= 0 and r["column_sum_exchange_ms"] > 0 and r["host_enqueue_ms"] > 0
