@@ -23,7 +23,7 @@ static void usage()
 {
     std::cerr << "usage: nbody_run [dataset_id 0-5] [--data-dir DIR] [--file PATH] [--plummer N] [--seed S] [--resume SNAPSHOT]\n"
                  "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P] [--morton [--reorder-every M]]\n"
-                 "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once] [--particle-softening]\n"
+                 "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once | --auto] [--particle-softening]\n"
                  "                 [--devices D0,D1,...] [--ring] [--peer-copy]      rows sharded over several GPUs (library-owned exchange)\n";
 }
 
@@ -35,6 +35,7 @@ int main(int argc, char **argv)
     std::uint64_t seed = 0x5EED0003ull;
     float dt = nbody::kTimeTick, softening = nbody::kSofteningVersion3;  // the reference's constants
     bool pad = false, kdk = false, pair_once = false, particle_eps = false, ring = false, peer_copy = false, morton = false;
+    bool auto_mode = false;  // --auto: the library picks the force mode by body count (nbody_create_auto / NBODY_FORCE_AUTO)
     std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -54,6 +55,7 @@ int main(int argc, char **argv)
         else if (a == "--pad-reference") pad = true;
         else if (a == "--kdk") kdk = true;
         else if (a == "--pair-once") pair_once = true;
+        else if (a == "--auto") auto_mode = true;
         else if (a == "--particle-softening") particle_eps = true;
         else if (a == "--device") device = std::atoi(next().c_str());
         else if (a == "--devices") {
@@ -108,7 +110,7 @@ int main(int argc, char **argv)
 
         if (!devices.empty()) {  // rows sharded over the listed GPUs; everything per step happens inside the library
             nbody::MultiSystem ms;
-            ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy, 0, morton);
+            ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy, 0, morton, auto_mode);
             ms.setState(b.pos.data(), b.vel.data());
             if (morton && reorder_every > 0) ms.setReorderPeriod(reorder_every);
             ms.timing(true);
@@ -160,13 +162,15 @@ int main(int argc, char **argv)
             return 0;
         }
         nbody::System sys;
-        if (pair_once) sys.initializeShard(b.n(), 0, b.n(), nbody_pair_once_split_len(b.n()), device);
+        if (auto_mode) sys.initializeAuto(b.n(), device);   // initialize(numBodies), the force mode chosen by the library
+        else if (pair_once) sys.initializeShard(b.n(), 0, b.n(), nbody_pair_once_split_len(b.n()), device);
         else sys.initialize(b.n(), device);             // initialize(numBodies)
         sys.setParticlesPosition(b.pos.data());
         sys.setParticlesVelocity(b.vel.data());
         sys.timing(true);
         if (kdk) sys.setKickDriftKick(true);       // velocity Verlet instead of the reference's kick-drift
-        if (pair_once) sys.setPairOnce(true);      // the experimental pair-once force kernel
+        if (pair_once && !auto_mode) sys.setPairOnce(true);  // the pair-once force kernel
+        if (auto_mode) std::printf("force mode: %s\n", sys.pairOnce() ? "pair-once" : "one-sided");
         if (particle_eps) {                        // the eps column of the velocity records (kernel.cu:223, 237), unused there
             std::vector<float> eps((size_t)b.n());
             for (std::int64_t i = 0; i < b.n(); ++i) eps[(size_t)i] = b.vel[4 * (size_t)i + 3];

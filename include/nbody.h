@@ -244,10 +244,10 @@ int nbody_force_mode(const nbody_ctx *ctx);
  * need more, smaller tiles to fill the chip), 2048 from N = 2^20 (half the partial sums: 2.2 % faster at equal memory)
  * and 4096 from 2^23, so that the partial sums of one pass (n_total^2 / split_len entries of 12 bytes over all contexts:
  * 6.4 GB at N = 2^20, 103 GB at N = 2^22) would still fit one GPU even in one summation part
- * (nbody_set_summation_parts; by default a single context holds 3.2 GB and 26 GB of them). */
+ * (nbody_set_summation_parts; by default a single context holds 4.8 GB and 26 GB of them). */
 int64_t nbody_pair_once_split_len(int64_t n_total);
 #define NBODY_SYM_GROUPS 8
-#define NBODY_PARTIAL_SUM_BUDGET_BYTES (4ll << 30) /* nbody_set_summation_parts(ctx, 0): the fewest parts that stay below */
+#define NBODY_PARTIAL_SUM_BUDGET_BYTES (5ll << 30) /* nbody_set_summation_parts(ctx, 0): the fewest parts that stay below */
 int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 /* The exchange buffer of the pair-once mode: NBODY_SYM_GROUPS x n_total x float4 on the device, group-major.
  * d_buf is borrowed (NULL: a buffer the context owns -- enough for a single context).  nbody_sym_reduce writes the
@@ -286,11 +286,13 @@ int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
  * summation and the combination stay behind the force pass.  The result does not change by a bit (the association is by
  * groups either way).  parts = 1: one launch, then the whole summation.  2: every group but the last, then the last (one
  * extra launch tail; the partial-sum arrays hold the whole pass: n^2 / split_len 12-byte entries, 6.4 GB at N = 2^20).
- * 4, 8: equal parts whose arrays live in two slots used in turn: 2/parts of that (4 parts: 3.2 GB at N = 2^20; 8 parts:
- * 26 GB at 2^22), for one launch tail (0.2-0.5 ms) per extra part (measured at N = 2^20 with 1024-body splits: 8 parts
- * cost ~1 % of the step against 1).  0, the default: automatic -- one launch while the whole
- * pass fits NBODY_PARTIAL_SUM_BUDGET_BYTES (4 GiB: up to N = 589 000 with 1024-body splits), else 4 parts if a half
- * does, else 8 (N = 2^20: 4 parts, 3.2 GB; N = 2^22: 8 parts, 26 GB).  Systems too small
+ * 4, 8: parts whose arrays live in two slots used in turn, for one launch tail (0.2-0.5 ms) per extra part (measured at
+ * N = 2^20 with 1024-body splits: 8 parts cost ~1 % of the step against 1).  8: equal parts, a quarter of the pass held
+ * (26 GB at N = 2^22).  4: 3 + 3 + 1 + 1 of the 8 groups -- what stays behind the force pass is the LAST part's summation,
+ * so the last part is one group (update_ms 0.3 instead of 0.5 ms at N = 2^20) and the two slots hold three groups each:
+ * 3/4 of the pass (4.8 GB at N = 2^20).  0, the default: automatic -- one launch while the whole pass fits
+ * NBODY_PARTIAL_SUM_BUDGET_BYTES (5 GiB: up to N = 650 000 with 1024-body splits), else 4 parts if 3/4 of it does, else 8
+ * (N = 2^20: 4 parts, 4.8 GB; N = 2^22: 8 parts, 26 GB).  Systems too small
  * for several launches, shards and column-range calls always take one part.  nbody_set_early_summation(on) is
  * nbody_set_summation_parts(on ? 0 : 1). */
 int nbody_set_summation_parts(nbody_ctx *ctx, int parts);

@@ -36,6 +36,16 @@ public:
         check(nbody_create(&ctx_, device, numBodies), "nbody_create");
         n_ = numBodies;
     }
+    // initialize(numBodies) with the faster force mode for this body count already selected (nbody_create_auto): the
+    // pair-once kernels from NBODY_PAIR_ONCE_MIN_BODIES bodies on, the one-sided ones below.
+    void initializeAuto(std::int64_t numBodies, int device = 0)
+    {
+        nbody_destroy(ctx_);
+        ctx_ = nullptr;
+        check(nbody_create_auto(&ctx_, device, numBodies), "nbody_create_auto");
+        n_ = numBodies;
+    }
+    bool pairOnce() const { return nbody_force_mode(ctx_) == NBODY_FORCE_SYMMETRIC; }
     // One rank of a sharded run: rows [rowLo, rowLo+rowCount) against all numBodies columns.
     void initializeShard(std::int64_t numBodies, std::int64_t rowLo, std::int64_t rowCount, std::int64_t splitLen = 0,
                          int device = 0)
@@ -131,14 +141,15 @@ public:
 
     // initialize(numBodies) on the given devices; pairOnce / kickDriftKick / ring / peerCopy select the variants
     void initialize(std::int64_t numBodies, const std::vector<int> &devices, bool pairOnce = false, bool kickDriftKick = false,
-                    bool ring = false, bool peerCopy = false, std::int64_t splitLen = 0, bool mortonOrder = false)
+                    bool ring = false, bool peerCopy = false, std::int64_t splitLen = 0, bool mortonOrder = false,
+                    bool autoMode = false)
     {
         nbody_multi_destroy(m_);
         m_ = nullptr;
         nbody_multi_config cfg{};
         cfg.n_bodies = numBodies;
         cfg.split_len = splitLen;
-        cfg.force_mode = pairOnce ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED;
+        cfg.force_mode = autoMode ? NBODY_FORCE_AUTO : pairOnce ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED;
         cfg.integrator = kickDriftKick ? NBODY_INTEGRATOR_KDK : NBODY_INTEGRATOR_KICK_DRIFT;
         cfg.exchange = ring ? NBODY_EXCHANGE_RING : NBODY_EXCHANGE_ALLGATHER;
         cfg.transport = peerCopy ? NBODY_TRANSPORT_PEER_COPY : NBODY_TRANSPORT_RCCL;
@@ -147,6 +158,9 @@ public:
         n_ = numBodies;
     }
     void setState(const float *xyzm, const float *xyzw) { check(nbody_multi_set_state(m_, xyzm, xyzw), "nbody_multi_set_state"); }
+    // the reference's two setters, independent copies (kernel.cu:163-188)
+    void setParticlesPosition(const float *xyzm) { check(nbody_multi_set_positions(m_, xyzm), "nbody_multi_set_positions"); }
+    void setParticlesVelocity(const float *xyzw) { check(nbody_multi_set_velocities(m_, xyzw), "nbody_multi_set_velocities"); }
     void setParticleSoftening(const float *hostEps)
     {
         check(nbody_multi_set_particle_softening(m_, hostEps), "nbody_multi_set_particle_softening");

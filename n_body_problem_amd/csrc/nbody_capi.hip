@@ -797,8 +797,30 @@ int nbody_sym_reduce(nbody_ctx *c)
     return NBODY_OK;
 }
 
+// Pair-once mode: what is still missing of the group sums -- the column-side sums of the last part (unless nbody_sym_reduce
+// has run: a shard exchanges them first) and the row-side sums of its rows.  After it rowsum[g][b] and colparts[g][b] hold
+// every group's two halves for the context's rows.
+static int sym_group_sums(nbody_ctx *c, const char *who)
+{
+    if (!c->sym_reduced) {
+        if (c->row_lo != 0 || c->row_count != c->n_total)
+            return fail(c, NBODY_ERR_STATE, std::string(who) + ": pair-once mode on a shard: call nbody_sym_reduce and exchange "
+                                                                 "the column sums first");
+        int rc = nbody_sym_reduce(c);
+        if (rc != NBODY_OK)
+            return rc;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const nbody_ctx::SymPart &p = *c->pending;
+    HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + p.row_off, c->rowsum + p.b0,
+                                 (int)(c->row_lo + p.b0), (int)p.rows, (int)c->split_len, c->n_splits, c->group_splits,
+                                 (int)c->row_count, c->stream));
+    c->sym_reduced = false;
+    return NBODY_OK;
+}
+
 // The partial sums the update kernels add up: the [n_splits][row_count] array of the one-sided kernel, or, in the
-// pair-once mode, the one "split" sym_finalize produces from the row sums and the (exchanged) column sums.
+// pair-once mode, the one "split" sym_combine produces from the row sums and the (exchanged) column sums.
 static int summed_partials(nbody_ctx *c, const char *who, const float4 **partials, int *n_splits)
 {
     int rc = all_splits_done(c, who);
@@ -809,23 +831,12 @@ static int summed_partials(nbody_ctx *c, const char *who, const float4 **partial
         *n_splits = c->n_splits;
         return NBODY_OK;
     }
-    if (!c->sym_reduced) {
-        if (c->row_lo != 0 || c->row_count != c->n_total)
-            return fail(c, NBODY_ERR_STATE, std::string(who) + ": pair-once mode on a shard: call nbody_sym_reduce and exchange "
-                                                                 "the column sums first");
-        rc = nbody_sym_reduce(c);
-        if (rc != NBODY_OK)
-            return rc;
-    }
-    HIP_TRY(c, hipSetDevice(c->device));
+    rc = sym_group_sums(c, who);
+    if (rc != NBODY_OK)
+        return rc;
     const int n_groups = (c->n_splits + c->group_splits - 1) / c->group_splits;
-    const nbody_ctx::SymPart &p = *c->pending;
-    HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + p.row_off, c->rowsum + p.b0,
-                                 (int)(c->row_lo + p.b0), (int)p.rows, (int)c->split_len, c->n_splits, c->group_splits,
-                                 (int)c->row_count, c->stream));
     HIP_TRY(c, launch_sym_combine(c->rowsum, c->colparts, c->sym_acc, (int)c->row_lo, (int)c->row_count, (int)c->n_total, n_groups,
                                   c->stream));
-    c->sym_reduced = false;
     *partials = c->sym_acc;
     *n_splits = 1;
     return NBODY_OK;
@@ -922,12 +933,10 @@ static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
     const int64_t blocks4 = (c->row_count + (int64_t)kTile * 4 - 1) / ((int64_t)kTile * 4) * split_count;
     if (blocks4 >= want[0])
         return 4;
-    // too few 1024-row workgroups: the same packed loop with one wave (256 rows) per workgroup, once there are about three
-    // waves per SIMD to deal out (N = 20 225: 6320 waves, 90 against 124 us per pass with one row per lane); below that the
-    // one-row kernel spreads a small system over more SIMDs (profiles/r03_small_n_blocking.txt)
-    static const int64_t w1_min = getenv("NBODY_W1_MIN_WAVES") ? atoll(getenv("NBODY_W1_MIN_WAVES")) : 12;
-    const int64_t waves1 = (c->row_count + kTile - 1) / kTile * split_count;
-    if (!c->eps_pp && waves1 >= w1_min * c->cu_count)
+    // too few 1024-row workgroups: the same packed loop with one wave (256 rows) per workgroup -- at every size below (N =
+    // 4096 ... 20 225: 29 / 34 / 59 / 78 / 121 us per step against 42 / 38 / 73 / 89 / 137 with the compiler-allocated one-row
+    // kernel, profiles/r03_small_n_blocking*.txt).  Per-particle softening runs on the compiler-allocated kernels only.
+    if (!c->eps_pp)
         return 41;
     const int64_t blocks2 = (c->row_count + (int64_t)kTile * 2 - 1) / ((int64_t)kTile * 2) * split_count;
     return blocks2 >= want[1] ? 2 : 1;
@@ -1061,7 +1070,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             int K = c->sum_parts;
             if (K == 0) {  // automatic: one launch is the fastest (profiles/r02_summation_parts_eight_rows.txt); more only for memory
                 const double pass_bytes = 12.0 * (double)c->n_total * (double)c->n_total / (double)L;
-                K = pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 1 : pass_bytes / 2 <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 4 : 8;
+                // 4 parts of 3 + 3 + 1 + 1 groups hold two slots of three groups = 3/4 of the pass; 8 equal parts a quarter
+                K = pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 1 : 0.75 * pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 4 : 8;
             }
             // below 32768 tiles (N = 2^18) an extra launch costs more than the summation it hides; the variable is for tests
             const char *min_env = getenv("NBODY_SYM_PARTS_MIN_TILES");
@@ -1079,6 +1089,13 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 } else if (K == 2) {
                     part.g0 = p ? n_groups - 1 : 0;
                     part.g1 = p ? n_groups : n_groups - 1;
+                } else if (K == 4 && n_groups == 8) {
+                    // 3 + 3 + 1 + 1 groups: what stays behind the force pass is the LAST part's summation (its partial sums are
+                    // read back at HBM speed: 0.2 GB per group and per million bodies^2 / split_len), so the last part is one
+                    // group, not two -- update_ms 0.50 -> 0.3 ms at N = 2^20 -- and the two slots hold three groups each
+                    static const int cut[5] = {0, 3, 6, 7, 8};
+                    part.g0 = cut[p];
+                    part.g1 = cut[p + 1];
                 } else {
                     part.g0 = p * (n_groups / K);
                     part.g1 = (p + 1) * (n_groups / K);
@@ -1141,8 +1158,13 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         // one-column loops (170 ms) -- A/B measurement
         static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 2;
         sa.packed = c->rows_per_lane == 8 ? 2 : c->rows_per_lane == 4 ? 1 : packed_env;  // nbody_set_rows_per_lane: A/B in one process
+        // Equal-mass path off: no tile can take the equal-mass loop -- the eight-row loop for arbitrary masses (its own kernel:
+        // three waves per SIMD; splits of whole 1024 bodies, else the four-row kernel).  The switch is also the way to give a
+        // body set WITHOUT one-mass splits (a continuous mass spectrum) the eight-row loop: with the path on, such tiles take
+        // the four-row loop inside the equal-mass kernel.  NBODY_SYM_GENERAL8=0: the four-row kernel (A/B).
+        static const bool general8 = !(getenv("NBODY_SYM_GENERAL8") && atoi(getenv("NBODY_SYM_GENERAL8")) == 0);
         if (sa.packed == 2 && !c->equal_mass_path)
-            sa.packed = 1;  // no tile can take the eight-row loop: the four-row kernel (5 waves per SIMD) runs the general loop 1 % faster
+            sa.packed = general8 ? 3 : 1;
         auto part_args = [&](const nbody_ctx::SymPart &p) {
             sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;
             sa.col_partials = c->col_partials + p.col_off;
@@ -1287,13 +1309,24 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
     HIP_TRY(c, hipSetDevice(c->device));
     {
         TimedLaunch t(c, &c->ev_update, &c->update_ms, &c->update_launches);
-        const float4 *partials;
-        int n_splits;
-        int rc = summed_partials(c, "nbody_update", &partials, &n_splits);
-        if (rc != NBODY_OK)
-            return rc;
-        HIP_TRY(c, launch_update(reinterpret_cast<float4 *>(d_pos), reinterpret_cast<float4 *>(d_vel), partials,
-                                 (int)c->row_lo, (int)c->row_count, n_splits, dt, c->stream));
+        if (c->force_mode == NBODY_FORCE_SYMMETRIC) {  // the combination of the group sums rides in the update kernel
+            int rc = all_splits_done(c, "nbody_update");
+            if (rc == NBODY_OK)
+                rc = sym_group_sums(c, "nbody_update");
+            if (rc != NBODY_OK)
+                return rc;
+            const int n_groups = (c->n_splits + c->group_splits - 1) / c->group_splits;
+            HIP_TRY(c, launch_update_sym(reinterpret_cast<float4 *>(d_pos), reinterpret_cast<float4 *>(d_vel), c->rowsum, c->colparts,
+                                         (int)c->row_lo, (int)c->row_count, (int)c->n_total, n_groups, dt, c->stream));
+        } else {
+            const float4 *partials;
+            int n_splits;
+            int rc = summed_partials(c, "nbody_update", &partials, &n_splits);
+            if (rc != NBODY_OK)
+                return rc;
+            HIP_TRY(c, launch_update(reinterpret_cast<float4 *>(d_pos), reinterpret_cast<float4 *>(d_vel), partials,
+                                     (int)c->row_lo, (int)c->row_count, n_splits, dt, c->stream));
+        }
     }
     std::fill(c->split_done.begin(), c->split_done.end(), 0);
     return NBODY_OK;

@@ -76,7 +76,8 @@ struct SymArgs {
     const float *eps_pp;   // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
     const float *split_mass;  // [n_splits]: the one mass of a split's bodies, or NaN (launch_split_mass)
     int packed;               // 0: one-column loops; 1: packed two-columns-per-step loops, four rows per lane; 2 (default): and
-                              // eight rows per lane on equal-mass tiles of splits >= 1024 bodies
+                              // eight rows per lane on equal-mass tiles of splits >= 1024 bodies; 3: eight rows per lane on
+                              // every tile of such splits (the kernel allocated for three waves per SIMD)
 };
 // split_mass[s] for every split of the body set, from the masses now in pos (O(N); see split_mass_kernel)
 hipError_t launch_split_mass(const float4 *pos, float *split_mass, int n_total, int split_len, bool enabled, hipStream_t stream);
@@ -104,6 +105,10 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
 // Sum the partials of n_splits splits in ascending order and kick-drift rows of this context.
 hipError_t launch_update(float4 *pos_all, float4 *vel_rows, const float4 *partials, int row_lo, int row_count,
                          int n_splits, float dt, hipStream_t stream);
+
+// Pair-once mode: the combination of the group sums (launch_sym_combine's association) and the kick-drift in one launch.
+hipError_t launch_update_sym(float4 *pos_all, float4 *vel_rows, const float4 *rowsum, const float4 *colparts, int row_lo,
+                             int row_count, int n_total, int n_groups, float dt, hipStream_t stream);
 
 // Velocity-Verlet (kick-drift-kick) pieces with cached accelerations (the reference's historical
 // variant, unused_files/backup.cu:859-887 driven at :1848-1866, spends two force evaluations per step).

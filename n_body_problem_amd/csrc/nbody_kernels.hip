@@ -470,10 +470,12 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
 // partner) and runs the identical hand-allocated loop, so each row's sum is the same FMA chain: not a bit changes.
 // Splits of exactly one tile (split_len = 256, every system below 32 768 bodies) need no split_mass_kernel launch in front:
 // the wave holds the split's 256 masses in registers and forms the same flag itself (one launch less per step).
-template <bool GUARD>
+// ONE_TILE: every split is one 256-column tile (split_len = 256): no second LDS buffer, no columns in flight under the
+// loop -- 16 VGPRs and 4 KiB of LDS less, so that the six or seven waves a SIMD gets at N = 20 225 are all resident at once.
+template <bool GUARD, bool ONE_TILE>
 __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
 {
-    __shared__ float4 tile[2 * kTile + 1];
+    __shared__ float4 tile[(ONE_TILE ? 1 : 2) * kTile + 1];
 
     const int lane = threadIdx.x;
     int split = a.split_first + blockIdx.y;
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
         split += a.skip_count;
     const int j0 = split * a.split_len;
     const int j1 = min(j0 + a.split_len, a.n_total);
-    const int ntiles = (j1 - j0 + kTile - 1) / kTile;
+    const int ntiles = ONE_TILE ? 1 : (j1 - j0 + kTile - 1) / kTile;
     const int row_base = blockIdx.x * kTile + 4 * (lane & 15) + (lane >> 4);  // rows row_base + 64 k: see force_kernel_r4pk
 
     float4 p[4];
@@ -529,11 +531,11 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
     for (int k = 0; k < 4; ++k)
         tile[k * 64 + lane] = stage[k];
     if (lane == 0)
-        tile[2 * kTile] = make_float4(0.f, 0.f, 0.f, 0.f);
+        tile[(ONE_TILE ? 1 : 2) * kTile] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) {  // in flight under the tile's arithmetic
+        if (!ONE_TILE && t + 1 < ntiles) {  // in flight under the tile's arithmetic
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = j0 + (t + 1) * kTile + k * 64 + lane;
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
                     stage[k] = a.pos[c];
             }
         }
-        unsigned lds = (unsigned)(size_t)(&tile[(t & 1) * kTile]);
+        unsigned lds = (unsigned)(size_t)(&tile[ONE_TILE ? 0 : (t & 1) * kTile]);
         unsigned cnt;
 #define PK_OPERANDS                                                                                                   \
         : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),          \
@@ -558,12 +560,13 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
         else
             asm volatile(PK_TILE_LOOP(PK_NOGUARD, PK_POST) PK_OPERANDS);
 #undef PK_OPERANDS
-        if (t + 1 < ntiles) {
+        if (!ONE_TILE && t + 1 < ntiles) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 tile[((t + 1) & 1) * kTile + k * 64 + lane] = stage[k];
         }
-        __syncthreads();
+        if (!ONE_TILE)
+            __syncthreads();
     }
 
     float4 *out = a.partials + (size_t)split * a.row_count;
@@ -577,10 +580,16 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
 static hipError_t launch_forces_r4pk_w1(const ForceArgs &a, hipStream_t stream)
 {
     dim3 grid((a.row_count + kTile - 1) / kTile, a.split_count, 1);
-    if (a.eps2 > 0.f)
-        hipLaunchKernelGGL(force_kernel_r4pk_w1<false>, grid, dim3(64), 0, stream, a);
-    else
-        hipLaunchKernelGGL(force_kernel_r4pk_w1<true>, grid, dim3(64), 0, stream, a);
+    if (a.split_len == kTile) {
+        if (a.eps2 > 0.f)
+            hipLaunchKernelGGL((force_kernel_r4pk_w1<false, true>), grid, dim3(64), 0, stream, a);
+        else
+            hipLaunchKernelGGL((force_kernel_r4pk_w1<true, true>), grid, dim3(64), 0, stream, a);
+    } else if (a.eps2 > 0.f) {
+        hipLaunchKernelGGL((force_kernel_r4pk_w1<false, false>), grid, dim3(64), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((force_kernel_r4pk_w1<true, false>), grid, dim3(64), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -705,6 +714,52 @@ hipError_t launch_update(float4 *pos_all, float4 *vel_rows, const float4 *partia
     else
         hipLaunchKernelGGL(update_kernel<kTile>, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, pos_all,
                            vel_rows, partials, row_lo, row_count, n_splits, dt);
+    return hipGetLastError();
+}
+
+// The pair-once mode's last two passes in one: acc[b] = sum over the groups g (ascending) of ( rowsum[g][b] + colparts[g][b] )
+// -- sym_combine_kernel's association (nbody_symmetric.hip), so not a bit changes -- and the kick-drift of update_kernel,
+// without the round trip of the summed accelerations through memory and one launch less behind the force pass.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void update_sym_kernel(float4 *pos_all, float4 *vel_rows, const float4 *rowsum,
+                                                           const float4 *colparts, int row_lo, int row_count, int n_total,
+                                                           int n_groups, float dt)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= row_count)
+        return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int g = 0; g < n_groups; ++g) {
+        const float4 rs = rowsum[(size_t)g * row_count + r];
+        const float4 cp = colparts[(size_t)g * n_total + row_lo + r];
+        ax += rs.x + cp.x;
+        ay += rs.y + cp.y;
+        az += rs.z + cp.z;
+    }
+    float4 v = vel_rows[r];
+    float4 x = pos_all[row_lo + r];
+    const double h = (double)dt;
+    v.x = (float)__builtin_fma((double)ax, h, (double)v.x);
+    v.y = (float)__builtin_fma((double)ay, h, (double)v.y);
+    v.z = (float)__builtin_fma((double)az, h, (double)v.z);
+    x.x = (float)__builtin_fma((double)v.x, h, (double)x.x);
+    x.y = (float)__builtin_fma((double)v.y, h, (double)x.y);
+    x.z = (float)__builtin_fma((double)v.z, h, (double)x.z);
+    vel_rows[r] = v;
+    pos_all[row_lo + r] = x;
+}
+
+hipError_t launch_update_sym(float4 *pos_all, float4 *vel_rows, const float4 *rowsum, const float4 *colparts, int row_lo,
+                             int row_count, int n_total, int n_groups, float dt, hipStream_t stream)
+{
+    if (row_count <= 0)
+        return hipSuccess;
+    if (row_count < 256 * kTile)
+        hipLaunchKernelGGL(update_sym_kernel<64>, dim3((row_count + 63) / 64), dim3(64), 0, stream, pos_all, vel_rows, rowsum,
+                           colparts, row_lo, row_count, n_total, n_groups, dt);
+    else
+        hipLaunchKernelGGL(update_sym_kernel<kTile>, dim3((row_count + kTile - 1) / kTile), dim3(kTile), 0, stream, pos_all,
+                           vel_rows, rowsum, colparts, row_lo, row_count, n_total, n_groups, dt);
     return hipGetLastError();
 }
 

@@ -94,3 +94,26 @@ def test_committed_galaxy_file_against_the_reference_csv_rows(golden_dir):
         assert np.allclose(got, want, rtol=1e-5, atol=1e-12), i
     assert len(np.unique(pos[:, 3])) == 3                       # three mass species: halo, bulge, disk
     assert ic.padded_count(pos.shape[0]) == 20225               # kernel.cu:1130
+
+
+def test_committed_k17hp_and_stars_fixtures(golden_dir):
+    """The two further inputs of load_data that travel with the repo (tests/golden/README.md): k17hp.snap whole, the first
+    8192 records of stars.dat.  Known answers read off the files' own text; where the reference is on this machine, the
+    fixtures are its bytes / its tokens."""
+    import hashlib
+    p, v = ds.read_any(os.path.join(golden_dir, "k17hp.snap"))
+    assert p.shape == (10002, 4) and np.all(p[:, 3] == np.float32(2e-4)) and np.isclose(p[:, 3].sum(dtype=np.float64), 2.0004, rtol=1e-6)
+    tok = open(os.path.join(golden_dir, "k17hp.snap")).read().split()
+    assert (int(tok[0]), int(tok[1])) == (10002, 3)
+    first_pos = [float(x) for x in tok[3 + 10002:3 + 10002 + 3]]
+    assert np.allclose(p[0, :3], first_pos, rtol=1e-6) and np.allclose(v[-1, 3], float(tok[-1]), rtol=1e-6)   # eps of the last body
+    assert ic.padded_count(10002) == 10241
+    p, v = ds.read_any(os.path.join(golden_dir, "stars_8192.dat"))
+    first = [float(x) for x in open(os.path.join(golden_dir, "stars_8192.dat")).readline().split()]
+    assert p.shape == (8192, 4) and np.all(p[:, 3] == 1) and np.all(v[:, 3] == 0)
+    assert np.allclose(p[0, :3], first[2::-1], rtol=1e-6) and np.allclose(v[0, :3], first[5:2:-1], rtol=1e-6)   # z y x order on disk
+    if os.path.isdir(REF_DATA):
+        sha = lambda f: hashlib.sha256(open(f, "rb").read()).hexdigest()
+        assert sha(os.path.join(golden_dir, "k17hp.snap")) == sha(os.path.join(REF_DATA, "k17hp.snap"))
+        full, _ = ds.read_dat(os.path.join(REF_DATA, "stars.dat"))
+        assert np.array_equal(full[:8192], p)
