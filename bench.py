@@ -344,6 +344,9 @@ def main():
     ap.add_argument("--force-mode", default=os.environ.get("NBODY_FORCE_MODE", "pair_once"),
                     choices=["pair_once", "one_sided", "symmetric"],
                     help="pair_once (= symmetric): each unordered pair once; one_sided: every ordered interaction")
+    ap.add_argument("--no-equal-mass-path", action="store_true",
+                    help="send every split down the general-mass inner loops (what a body set with arbitrary masses gets; the "
+                         "N = 1 run reports it as the general_mass_path leg anyway -- this makes it the main measurement, for profiling)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sanity", action="store_true", help="skip the energy / replica checks around the timed region")
@@ -416,6 +419,9 @@ def main():
         if args.reorder_every and hasattr(system, "set_reorder_period"):
             system.set_reorder_period(args.reorder_every)
         kernels.set_rows_per_lane(args.rows_per_lane)
+        if args.no_equal_mass_path:
+            for k in ([system.shard(i) for i in range(system.local_ranks)] if library_exchange else [kernels]):
+                k.set_equal_mass_path(False)
         system.setParticlesPosition(pos)
         system.setParticlesVelocity(vel)
         info = kernels.device_info()
@@ -512,13 +518,13 @@ def main():
                        "exchange_timeout_s": args.exchange_timeout if library_exchange else None,
                        "rccl_ranks": rccl_ranks,
                        "split_len": int(getattr(system, "split_len", 0)), "seed": nb.CONFIG_SEED[3],
-                       "force_mode": mode,
+                       "force_mode": mode, "equal_mass_path": not args.no_equal_mass_path,
                        # the layout the library keeps the generator's bodies in (laid on the device at upload, undone at
                        # download; the other order is the `other_body_order` leg of the N = 1 run)
                        "body_order": getattr(system, "body_order", "given"),
                        "reorder_every": args.reorder_every or None},
             "roofline": roofline(mode, n, int(getattr(system, "split_len", 0)), rows_here, args.steps, tm,
-                                 equal_mass=bool(np.all(pos[:, 3] == pos[0, 3]))),
+                                 equal_mass=bool(np.all(pos[:, 3] == pos[0, 3])) and not args.no_equal_mass_path),
             "force_only_interactions_per_s": rows_here * n * args.steps / force_s * world,
             "update_ms_per_step": tm["update_ms"] / args.steps,
             "overlapped_aux_ms_per_step": tm.get("aux_ms", 0.0) / args.steps,   # diagonal tiles + early summation, beside the tiles

@@ -1153,18 +1153,19 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.eps2 = softening * softening;
         sa.eps_pp = c->eps_pp;
         sa.split_mass = c->split_mass;
-        // 2 (default): packed two-columns-per-step loops, equal-mass tiles of splits of 1024 bodies and more with eight rows
-        // per lane (161 against 167 ms per N = 2^20 pass); NBODY_SYM_PACKED=1 keeps four rows per lane everywhere, 0 the
-        // one-column loops (170 ms) -- A/B measurement
-        static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 2;
-        sa.packed = c->rows_per_lane == 8 ? 2 : c->rows_per_lane == 4 ? 1 : packed_env;  // nbody_set_rows_per_lane: A/B in one process
-        // Equal-mass path off: no tile can take the equal-mass loop -- the eight-row loop for arbitrary masses (its own kernel:
-        // three waves per SIMD; splits of whole 1024 bodies, else the four-row kernel).  The switch is also the way to give a
-        // body set WITHOUT one-mass splits (a continuous mass spectrum) the eight-row loop: with the path on, such tiles take
-        // the four-row loop inside the equal-mass kernel.  NBODY_SYM_GENERAL8=0: the four-row kernel (A/B).
+        // 3 (default): packed two-columns-per-step loops, eight rows per lane on every tile of splits of whole 1024 bodies -- one
+        // kernel holds the equal-mass loop (S8) and the loop for arbitrary masses (S9), allocated for three waves per SIMD, which
+        // costs the equal-mass loop 0.1 % against its own four-waves kernel (144.33 / 144.39 against 144.17 / 144.19 ms per
+        // N = 2^20 pass, profiles/r03_ab_packed3_equal_mass.txt) and gives every tile with arbitrary masses the eight-row loop
+        // (164.0 against 176.2 ms with the four-row loop, profiles/r03_ab_general_mass_eight_rows.txt).  NBODY_SYM_PACKED=2:
+        // round 2's arrangement (equal-mass tiles eight rows in a four-waves kernel, the others four rows); 1: four rows per lane
+        // everywhere; 0: the one-column loops -- A/B measurement.  NBODY_SYM_GENERAL8=0: with the equal-mass path off, the
+        // four-row kernel.
+        static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 3;
+        sa.packed = c->rows_per_lane == 8 ? 3 : c->rows_per_lane == 4 ? 1 : packed_env;  // nbody_set_rows_per_lane: A/B in one process
         static const bool general8 = !(getenv("NBODY_SYM_GENERAL8") && atoi(getenv("NBODY_SYM_GENERAL8")) == 0);
-        if (sa.packed == 2 && !c->equal_mass_path)
-            sa.packed = general8 ? 3 : 1;
+        if (sa.packed >= 2 && !c->equal_mass_path)
+            sa.packed = general8 ? 3 : 1;  // no tile can take the equal-mass loop
         auto part_args = [&](const nbody_ctx::SymPart &p) {
             sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;
             sa.col_partials = c->col_partials + p.col_off;

@@ -75,9 +75,9 @@ struct SymArgs {
     float eps2;
     const float *eps_pp;   // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
     const float *split_mass;  // [n_splits]: the one mass of a split's bodies, or NaN (launch_split_mass)
-    int packed;               // 0: one-column loops; 1: packed two-columns-per-step loops, four rows per lane; 2 (default): and
-                              // eight rows per lane on equal-mass tiles of splits >= 1024 bodies; 3: eight rows per lane on
-                              // every tile of such splits (the kernel allocated for three waves per SIMD)
+    int packed;               // 0: one-column loops; 1: packed two-columns-per-step loops, four rows per lane; 2: and eight rows
+                              // per lane on equal-mass tiles of splits of whole 1024 bodies; 3 (default): eight rows per lane
+                              // on every tile of such splits (one kernel, allocated for three waves per SIMD)
 };
 // split_mass[s] for every split of the body set, from the masses now in pos (O(N); see split_mass_kernel)
 hipError_t launch_split_mass(const float4 *pos, float *split_mass, int n_total, int split_len, bool enabled, hipStream_t stream);

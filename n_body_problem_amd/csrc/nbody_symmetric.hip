@@ -1,4 +1,4 @@
-// nbody_symmetric.hip -- EXPERIMENTAL pair-once force kernel.
+// nbody_symmetric.hip -- the pair-once force kernels: the headline force mode of bench.py.
 //
 // The reference's own contribution ("method C", main_project/kernel.cu:703-774) evaluates each unordered pair
 // once on an upper-triangular grid of 256 x 256 tiles and applies it to both bodies (Newton's third law) through
@@ -12,21 +12,27 @@
 //     each unordered pair {R, C} is one tile, with the side sym_rows_side() names as rows -- so that the tiles of a
 //     context that owns the rows of some splits are exactly the ones with R among them (sharding over GPUs: the
 //     P_col of remote bodies are summed per group of splits, exchanged once per step and added in a fixed order);
-//   * inside a wave, lane l owns 4 rows and at step s meets column (l+s) mod 64 of the wave's current 64-column
-//     group; the three column accumulators travel with the column, one lane per step (ds_bpermute_b32), so after 64
-//     steps column c's sum sits in lane c and is added to the LDS array without conflicts;
+//   * inside a wave, lane l owns 4 or 8 rows and meets the columns of the wave's current 64-column group one step at a
+//     time -- column (l+s) mod 64 at step s in the one-column loops, columns (l+s) and (l+s+32) mod 64 at step s = 0..31
+//     in the packed loops (the defaults), where every v_pk_*_f32 serves both; the column accumulators travel with their
+//     columns, one lane per step (ds_bpermute_b32), so after the last step a column's sum sits in one lane and is added to
+//     the LDS array without conflicts;
 //   * the 4 waves walk the column groups in a rotated order, G/4 groups apart, with a barrier every G/4 groups, so
 //     no two waves touch the same LDS entries at a time and every entry receives its terms in a fixed order:
 //     bit-reproducible;
-//   * small workgroups and <= 28 KiB of LDS (split_len 2048) put 5 workgroups = 5 waves per SIMD on a CU, enough for
-//     the idle-gap schedule of force_kernel_r4 to hide each wave's slow window after its
-//     v_rsq_f32 batch;
+//   * small workgroups and 33 KiB of LDS (split_len 2048: 8 KiB of per-wave stages + 24 KiB of column sums) put 4-5
+//     workgroups = 4-5 waves per SIMD on a CU (3 for the eight-row loop with arbitrary masses), enough for the phased
+//     schedule of force_kernel_r4 to hide each wave's slow window after its v_rsq_f32 batch;
 //   * diagonal tiles (R == C) are a separate, compiler-scheduled kernel that visits every (row, column) combination
 //     and keeps the pairs with row index < column index (1/n_splits of the work); the same kernel, without the mask,
 //     computes every tile when per-particle softening is on.
 //
-// Per unordered pair: 3 sub, 3 fma, rsq, 4 mul, 6 fma = 16 VALU + 1 transcendental (+ 3 DPP moves and 2 address
-// operations per 64 x 4 pairs) against 2 x (12 + 1) for the two ordered interactions it replaces.
+// Per unordered pair: 3 sub, 3 fma, rsq, 4 mul, 6 fma = 16 fp32 operations + 1 transcendental (14 + 1 on tiles whose two
+// splits each carry one mass), issued as 8 (7) packed instructions in the default loops, plus three LDS reads and six
+// ds_bpermute_b32 per step of 8 or 16 pairs -- against 2 x (12 + 1) for the two ordered interactions it replaces.
+// Loops, in the order they appear: SY_* one column per step (kept for A/B and eps = 0) . S2_* packed, equal-mass tiles .
+// S8_* the same with eight rows per lane (the headline loop) . S9_* eight rows, arbitrary masses . S3_* packed four rows,
+// arbitrary masses.
 #include "nbody_kernels.h"
 
 #include <cstdlib>

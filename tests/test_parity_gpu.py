@@ -974,48 +974,48 @@ def test_c_abi_auto_mode_lands_on_the_fast_kernels(nb, oracle_mod):
 
 @pytest.mark.parametrize("n,split_len", [(16384, 1024), (16384, 2048), (21000, 1024), (12288, 2048)])
 def test_eight_row_loop_for_arbitrary_masses(nb, oracle_mod, n, split_len):
-    """Round 3: with the equal-mass path off, tiles of splits of whole 1024 bodies run the eight-rows-per-lane loop for arbitrary
-    masses (S9_GROUP_LOOP, its own kernel allocated for three waves per SIMD: 2048-body splits four waves per workgroup, 1024
-    two).  Random masses, massless bodies and a ragged last split: against the fp64 truth, against the four-row loops (the path
-    on: no tile of this body set is one-mass) to rounding, two shards = one context bit for bit, and run to run."""
+    """Round 3: tiles of splits of whole 1024 bodies run eight rows per lane whatever their masses -- the equal-mass loop or
+    the loop for arbitrary masses (S9_GROUP_LOOP), both in one kernel allocated for three waves per SIMD (2048-body splits:
+    four waves per workgroup, 1024: two).  Random masses, massless bodies and a ragged last split: against the fp64 truth;
+    against the four-row loops (nbody_set_rows_per_lane(4)) to rounding; the equal-mass switch changes nothing when no tile is
+    one-mass; two shards = one context bit for bit; and run to run."""
     from n_body_problem_amd.multi import MultiGpuSystem
     pos, vel = nb.plummer(n, seed=41)
     rng = np.random.default_rng(41)
     pos[:, 3] *= rng.uniform(0.2, 3.0, n).astype(np.float32)
     pos[rng.integers(0, n, 50), 3] = 0.0
     acc, state = {}, {}
-    for on in (False, True, False):
+    for how in ("eight", "eight, equal-mass path off", "four", "eight again"):
         with nb.NBodySystem(n, split_len=split_len) as s:
             s.set_force_mode("pair_once")
-            s.set_equal_mass_path(on)
+            s.set_equal_mass_path(how != "eight, equal-mass path off")
+            s.set_rows_per_lane(4 if how == "four" else 0)
             s.setParticlesPosition(pos)
             s.setParticlesVelocity(np.zeros_like(vel))
             s.step(1.0, 1e-2)
-            a = s.download()[1][:, :3].astype(np.float64)
+            acc[how] = s.download()[1][:, :3].astype(np.float64)
             s.setParticlesPosition(pos)
             s.setParticlesVelocity(vel)
             s.step_n(3, 1e-3, 1e-2)
-            st = s.download()
-        if on in acc:                                            # the second run with the path off: the same bits
-            assert np.array_equal(st[0], state[on][0]) and np.array_equal(st[1], state[on][1])
-        acc[on], state[on] = a, st
+            state[how] = s.download()
+    for other in ("eight, equal-mass path off", "eight again"):
+        assert np.array_equal(acc[other], acc["eight"]), other
+        assert np.array_equal(state[other][0], state["eight"][0]) and np.array_equal(state[other][1], state["eight"][1]), other
     a64 = oracle_mod.accel_f64(pos, eps=1e-2)
     scale = np.linalg.norm(a64)
-    assert np.linalg.norm(acc[False] - a64) / scale < TOL and np.linalg.norm(acc[True] - a64) / scale < TOL
-    assert 0 < np.linalg.norm(acc[False] - acc[True]) / scale < 1e-6      # another association of the same sums
+    assert np.linalg.norm(acc["eight"] - a64) / scale < TOL and np.linalg.norm(acc["four"] - a64) / scale < TOL
+    assert 0 < np.linalg.norm(acc["eight"] - acc["four"]) / scale < 1e-6  # another association of the same sums
     mass = pos[:, 3].astype(np.float64)
-    net = (mass[:, None] * acc[False]).sum(0)
-    assert np.all(np.abs(net) < 1e-5 * (mass[:, None] * np.abs(acc[False])).sum(0))   # every pair once, to both bodies
+    net = (mass[:, None] * acc["eight"]).sum(0)
+    assert np.all(np.abs(net) < 1e-5 * (mass[:, None] * np.abs(acc["eight"])).sum(0))   # every pair once, to both bodies
     pr, vr = oracle_mod.step_f32(pos, vel, 1e-3, 1e-2, nsteps=3)
-    assert rel_state_error(state[False][0], pr) < TOL and rel_state_error(state[False][1], vr) < TOL
+    assert rel_state_error(state["eight"][0], pr) < TOL and rel_state_error(state["eight"][1], vr) < TOL
     with MultiGpuSystem(n, devices=[0, 0], force_mode="pair_once", transport="peer_copy", split_len=split_len) as m:
-        for i in range(2):
-            m.shard(i).set_equal_mass_path(False)
         m.set_state(pos, vel)
         m.step_n(3, 1e-3, 1e-2)
         p, v = m.download()
         n_padded = m.n_padded
     if n_padded == n:
-        assert np.array_equal(p, state[False][0]) and np.array_equal(v, state[False][1])
+        assert np.array_equal(p, state["eight"][0]) and np.array_equal(v, state["eight"][1])
     else:                                                        # padded to whole groups: other split counts, the same physics
-        assert rel_state_error(p, state[False][0]) < 1e-6 and rel_state_error(v, state[False][1]) < 1e-6
+        assert rel_state_error(p, state["eight"][0]) < 1e-6 and rel_state_error(v, state["eight"][1]) < 1e-6

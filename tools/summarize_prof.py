@@ -50,7 +50,7 @@ def main(tag, rnd, n, kern="force_kernel", mode=""):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 durations.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-            if "update_kernel" in r["Kernel_Name"]:
+            if "update_kernel" in r["Kernel_Name"] or "update_sym_kernel" in r["Kernel_Name"]:   # one per step
                 steps += 1
     # launches of the force kernel per force pass (round 2: the pair-once mode launches its tiles in two parts)
     per_pass = max(1, round(len(durations) / steps)) if steps else 1
