@@ -25,7 +25,11 @@ update) over one synthetic Plummer-sphere state resident in HBM.  Rank 0 prints 
               host's cores on a row slab of the same workload (N = 1 run only).
 Multi-GPU: total N is fixed, rows are sharded over the ranks => "scaling": "strong".  With the nccl backend (the product
 path) every per-step exchange runs inside the library (nbody_multi_*, csrc/nbody_multi.hip: RCCL all-gather or ring);
-torch.distributed carries the RCCL id at start-up, the barriers and the max over ranks of the elapsed time.
+torch.distributed carries the RCCL id at start-up, the barriers and the max over ranks of the elapsed time.  The line then
+carries "per_rank" (every rank's kernels, exchange times and host enqueue time per step, from the library's own events) and
+"peer_copy_leg" (the same job from one process with hipMemcpyPeerAsync instead of RCCL, run in a child process after the
+ranks are done).  A rank whose exchange does not arrive within --exchange-timeout seconds (60) prints ONE JSON line with
+"error" and exits non-zero.  --transport peer_copy runs that secondary measurement as the main one (no launcher, no RCCL).
 """
 import argparse
 import glob

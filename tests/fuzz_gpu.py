@@ -2,7 +2,7 @@
 """Seeded random configurations through both force modes on one GPU: pair-once vs one-sided vs the fp64 oracle, two
 row-sharing contexts (hand-copied exchange) vs one, 1/2/4/8 summation parts, and 2-8 shards with the library-owned exchange (nbody_multi_*, peer
 copies) vs one context on the padded system.  Mass patterns: random, equal, a few species in index order (some splits
-take the equal-mass loop, some do not), massless and very heavy bodies.  python tools/fuzz_gpu.py [cases] [seed]"""
+take the equal-mass loop, some do not), massless and very heavy bodies.  python tests/fuzz_gpu.py [cases] [seed]"""
 import os
 import sys
 

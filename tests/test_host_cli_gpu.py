@@ -200,3 +200,36 @@ def test_config5_dry_run_two_ranks_on_one_gpu_with_snapshots(tmp_path):
     p2, v2, step2, time2 = ds.load_snapshot(str(tmp_path / "resumed.nbs"))
     assert step == step2 == 20 and time == pytest.approx(time2) and p.shape == (1 << 22, 4)
     assert np.array_equal(p, p2) and np.array_equal(v, v2)
+
+
+def test_cli_auto_flag_is_the_librarys_choice_of_force_mode(tmp_path):
+    """--auto = nbody_create_auto (one context) / NBODY_FORCE_AUTO in nbody_multi_config (--devices): the one-sided kernels
+    at the reference's own size, the pair-once kernels from 65 536 bodies on -- the same bits as initialize(force_mode="auto")."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd import datasets as ds
+    from n_body_problem_amd.multi import MultiGpuSystem
+    for n, want in ((6000, "one-sided"), (65536, "pair-once")):
+        pos, vel = nb.plummer(n, seed=94)
+        start = str(tmp_path / f"start_{n}.nbs")
+        ds.save_snapshot(start, pos, vel, step=0, time=0.0)
+        final = str(tmp_path / f"auto_{n}.nbs")
+        out = run_cli("--resume", start, "--steps", 3, "--dt", 1e-3, "--softening", 1e-3, "--auto", "--final", final)
+        assert f"force mode: {want}" in out
+        p, v, _, _ = ds.load_snapshot(final)
+        with nb.initialize(n, force_mode="auto") as s:
+            assert s.force_mode == want.replace("-", "_")
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(vel)
+            s.step_n(3, 1e-3, 1e-3)
+            want_p, want_v = s.download()
+        assert np.array_equal(p, want_p) and np.array_equal(v, want_v), n
+        final2 = str(tmp_path / f"auto_two_{n}.nbs")
+        run_cli("--resume", start, "--steps", 3, "--dt", 1e-3, "--softening", 1e-3, "--auto", "--devices", "0,0", "--peer-copy",
+                "--final", final2)
+        p2, v2, _, _ = ds.load_snapshot(final2)
+        with MultiGpuSystem(n, devices=[0, 0], force_mode="auto", transport="peer_copy") as m:
+            assert m.force_mode == want.replace("-", "_")
+            m.set_state(pos, vel)
+            m.step_n(3, 1e-3, 1e-3)
+            mp, mv = m.download()
+        assert np.array_equal(p2, mp) and np.array_equal(v2, mv), n

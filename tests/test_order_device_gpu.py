@@ -71,6 +71,7 @@ def cases(nb):
     q[:, 3] = 1.0
     out["a line"] = q
     out["one body"] = np.array([[0.5, -2.0, 3.0, 1.0]], np.float32)
+    out["no body"] = np.zeros((0, 4), np.float32)
     q, _ = nb.plummer(20000, seed=22)
     from n_body_problem_amd import initial_conditions as ic
     out["reference-style padding"] = ic.pad_reference_style(q, np.zeros_like(q))[0]   # 225 massless bodies at the origin
