@@ -265,9 +265,11 @@ int nbody_set_particle_softening(nbody_ctx *ctx, const float *d_eps);
 /* The same from n_total HOST floats, copied into a buffer the context owns (NULL switches it off). */
 int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);
 
-/* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default = 4, the kernel
- * with the hand-allocated, packed-fp32 inner loop; 40 = the same with one row per instruction; -4 = four rows with the
- * compiler-allocated loop).  Never changes a result bit. */
+/* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default: 4, the kernel with the
+ * hand-allocated, packed-fp32 inner loop, in 1024-row workgroups where those fill the chip and in one-wave workgroups of 256
+ * rows below that; 41 forces the one-wave form, 40 = the loop with one row per instruction, -4 = four rows with the
+ * compiler-allocated loop).  In the pair-once mode 4 selects the four-row loops, 8 the eight-row ones.  In the one-sided
+ * mode it never changes a result bit. */
 int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
 
 /* Equal-mass splits (on by default).  Before every force launch an O(N) pass notes, per split, whether all its bodies

@@ -17,9 +17,13 @@ ap.add_argument("--rank", type=int, default=3)
 ap.add_argument("--mode", default="pair_once")
 ap.add_argument("--split-len", type=int, nargs="*", default=[2048, 1024])
 ap.add_argument("--two-streams", action="store_true")
+ap.add_argument("--morton", action="store_true", help="the bodies along the Morton curve (what bench.py's default layout gives every rank)")
 args = ap.parse_args()
 n = args.bodies
 pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
+if args.morton:
+    perm = nb.morton_order(pos)
+    pos, vel = pos[perm].copy(), vel[perm].copy()
 for L in args.split_len:
     L = L or (nb.pair_once_split_len(n) if args.mode == "pair_once" else nb.default_split_len(n))
     geo = pair_once_geometry if args.mode == "pair_once" else shard_geometry
@@ -51,6 +55,6 @@ for L in args.split_len:
         torch.cuda.synchronize()
         if it:
             best = min(best, ev[0].elapsed_time(ev[1]))
-    print(f"N={n} rank {args.rank}/{args.world} mode={args.mode} split_len={L} two_streams={args.two_streams}: "
+    print(f"N={n} rank {args.rank}/{args.world} mode={args.mode} split_len={L} two_streams={args.two_streams} morton={args.morton}: "
           f"{best:.3f} ms per step share -> x{args.world} ranks = {float(n) * n / best / 1e9:.3f}e12 interactions/s")
     s.close()
