@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measured parity on the reference's own inputs (tests/golden: galaxy_20K.bin, k17hp.snap, stars_8192.dat), the reference's
+"""Measured parity on the reference's own inputs (tests/golden: galaxy_20K.bin, k17hp.snap, k17c.snap, stars_8192.dat), the reference's
 way: padded to roundup(n, 256) + 1 (kernel.cu:260-278), dt = 0.008, VERSION 3's effective softening 1e-2 (kernel.cu:63-66,
 665-692), K frames of the bracket kernel.cu:1225-1242.
 
@@ -40,7 +40,7 @@ def main():
     golden = os.path.join(ROOT, "tests", "golden")
     print(f"{'input':16s} {'frames':>6s} {'mode':10s} {'order':7s} | {'pos vs f64':>10s} {'vel vs f64':>10s} | "
           f"{'pos vs v3':>10s} {'vel vs v3':>10s} | oracle v3 vs f64: pos, vel")
-    for name, frame_list in (("galaxy_20K.bin", (1, 10)), ("k17hp.snap", (1, 10)), ("stars_8192.dat", (1, 2))):
+    for name, frame_list in (("galaxy_20K.bin", (1, 10)), ("k17hp.snap", (1, 10)), ("k17c.snap", (3,)), ("stars_8192.dat", (1, 2))):
         pos, vel = ds.read_any(os.path.join(golden, name))
         ppos, pvel = nb.pad_reference_style(pos, vel)
         n = pos.shape[0]

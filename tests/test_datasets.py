@@ -108,6 +108,10 @@ def test_committed_k17hp_and_stars_fixtures(golden_dir):
     first_pos = [float(x) for x in tok[3 + 10002:3 + 10002 + 3]]
     assert np.allclose(p[0, :3], first_pos, rtol=1e-6) and np.allclose(v[-1, 3], float(tok[-1]), rtol=1e-6)   # eps of the last body
     assert ic.padded_count(10002) == 10241
+    p, v = ds.read_any(os.path.join(golden_dir, "k17c.snap"))
+    assert p.shape == (32770, 4) and np.all(p[:, 3] == p[0, 3]) and np.isclose(p[:, 3].sum(dtype=np.float64), 2.0001, rtol=1e-4)
+    tok = open(os.path.join(golden_dir, "k17c.snap")).read().split()
+    assert (int(tok[0]), int(tok[1])) == (32770, 3) and np.allclose(p[0, :3], [float(x) for x in tok[3 + 32770:3 + 32770 + 3]], rtol=1e-6)
     p, v = ds.read_any(os.path.join(golden_dir, "stars_8192.dat"))
     first = [float(x) for x in open(os.path.join(golden_dir, "stars_8192.dat")).readline().split()]
     assert p.shape == (8192, 4) and np.all(p[:, 3] == 1) and np.all(v[:, 3] == 0)
@@ -115,5 +119,6 @@ def test_committed_k17hp_and_stars_fixtures(golden_dir):
     if os.path.isdir(REF_DATA):
         sha = lambda f: hashlib.sha256(open(f, "rb").read()).hexdigest()
         assert sha(os.path.join(golden_dir, "k17hp.snap")) == sha(os.path.join(REF_DATA, "k17hp.snap"))
+        assert sha(os.path.join(golden_dir, "k17c.snap")) == sha(os.path.join(REF_DATA, "k17c.snap"))
         full, _ = ds.read_dat(os.path.join(REF_DATA, "stars.dat"))
         assert np.array_equal(full[:8192], p)

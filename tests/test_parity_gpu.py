@@ -225,11 +225,12 @@ def test_reference_dataset_galaxy_20k_ten_steps(nb, oracle_mod, golden_dir, mode
 
 
 @pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
-@pytest.mark.parametrize("name,frames", [("k17hp.snap", 10), ("stars_8192.dat", 1)])
+@pytest.mark.parametrize("name,frames", [("k17hp.snap", 10), ("k17c.snap", 3), ("stars_8192.dat", 1)])
 def test_reference_datasets_k17hp_and_stars(nb, oracle_mod, golden_dir, name, frames, mode):
-    """Two more of the inputs load_data serves (kernel.cu:996-1011), as committed data fixtures (tests/golden/README.md):
-    k17hp.snap (load_data(5): 10 002 equal-mass bodies, through the .snap parser -- the reference feeds it to its .dat
-    parser) and the first 8192 records of stars.dat (load_data(3): "z y x vz vy vx", every mass 1).  Padded the
+    """The other inputs load_data serves (kernel.cu:996-1011), as committed data fixtures (tests/golden/README.md):
+    k17hp.snap and k17c.snap (load_data(5) and (4): 10 002 and 32 770 equal-mass bodies, through the .snap parser -- the
+    reference feeds them to its .dat parser; k17c for three frames, the CPU restatement of 32 770 bodies being
+    what takes the time) and the first 8192 records of stars.dat (load_data(3): "z y x vz vy vx", every mass 1).  Padded the
     reference's way, its dt and VERSION 3 softening, against the oracle's restatement of VERSION 3 and the fp64 truth.
     stars.dat with unit masses is a violent collapse at dt = 0.008 (speeds of 200 after two frames; the fp32 restatement
     itself is 5e-5 off the truth after two frames and 3 % after five), so it is held to ONE frame; k17hp to ten.  Measured
@@ -238,7 +239,7 @@ def test_reference_datasets_k17hp_and_stars(nb, oracle_mod, golden_dir, name, fr
     import os
     from n_body_problem_amd import datasets as ds
     pos, vel = ds.read_any(os.path.join(golden_dir, name))
-    assert pos.shape[0] == {"k17hp.snap": 10002, "stars_8192.dat": 8192}[name]
+    assert pos.shape[0] == {"k17hp.snap": 10002, "k17c.snap": 32770, "stars_8192.dat": 8192}[name]
     ppos, pvel = nb.pad_reference_style(pos, vel)
     n = pos.shape[0]
     p3, v3 = oracle_mod.step_v3(ppos, pvel, nsteps=frames)
