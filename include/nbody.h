@@ -227,7 +227,7 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
  * ceil(n_splits / 8) splits, a sharded context must own whole groups, and per step
  *     nbody_forces / nbody_forces_complement   (as in the default mode: any split-aligned column ranges)
  *     nbody_sym_reduce                          (column-side sums of the context's groups, for every body)
- *     [all-gather the contexts' slices of the colparts buffer -- the caller's job, e.g. RCCL]
+ *     [exchange the contexts' slices of the colparts buffer -- the caller's job, e.g. RCCL -- and, beside it, nbody_sym_rowsum]
  *     nbody_update / nbody_kdk_*                (adds row-side and column-side sums in the fixed order)
  * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
 /* NBODY_FORCE_AUTO (nbody_set_force_mode only; a context that owns every row, nothing pending): the pair-once mode from
@@ -256,6 +256,10 @@ int nbody_set_force_mode(nbody_ctx *ctx, int mode);
 int nbody_sym_set_colparts(nbody_ctx *ctx, float *d_buf);
 int nbody_sym_groups(const nbody_ctx *ctx, int64_t *group_lo, int64_t *group_count, int64_t *group_splits);
 int nbody_sym_reduce(nbody_ctx *ctx);
+/* Optional, after nbody_sym_reduce: the row-side sums of the context's rows now instead of inside nbody_update / nbody_kdk_*.
+ * They need the context's own partial sums only, so a sharded host runs them while the column-side sums are on the wire
+ * (nbody_multi_step does).  Not a bit changes. */
+int nbody_sym_rowsum(nbody_ctx *ctx);
 
 /* Per-particle softening: the reference loads a per-particle eps into velocities[4i+3]
  * (kernel.cu:223, 237) and no kernel ever reads it.  With d_eps (n_total floats on the device, borrowed until replaced;

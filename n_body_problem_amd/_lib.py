@@ -70,6 +70,7 @@ _PROTOTYPES = {
     "nbody_sym_groups": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_int64)]),
     "nbody_sym_reduce": (c_int, [c_void_p]),
+    "nbody_sym_rowsum": (c_int, [c_void_p]),
     "nbody_set_particle_softening": (c_int, [c_void_p, c_void_p]),
     "nbody_upload_particle_softening": (c_int, [c_void_p, c_void_p]),
     "nbody_set_rows_per_lane": (c_int, [c_void_p, c_int]),

@@ -56,6 +56,7 @@ struct nbody_ctx {
     float4 *rowsum = nullptr;        // [kSymGroups][row_count]: row-side sums per column group (launch_sym_rowsum)
     float *split_mass = nullptr;     // [n_splits]: the one mass of each split's bodies or NaN (pair-once tiles' fast path)
     bool sym_reduced = false;        // nbody_sym_reduce has run since the last forces
+    bool sym_rows_summed = false;    // ... and nbody_sym_rowsum (the row-side sums of the last part)
     int group_splits = 1, group_lo = 0, group_count = 0;
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
@@ -681,7 +682,7 @@ static int resplit(nbody_ctx *c, int64_t split_len)
     c->split_mass = nullptr;
     HIP_TRY(c, hipMalloc((void **)&c->split_mass, sizeof(float) * (size_t)std::max(1, c->n_splits)));
     c->force_mode = NBODY_FORCE_ONE_SIDED;  // the pair-once geometry (groups of splits) is set up again by the caller
-    c->sym_reduced = false;
+    c->sym_reduced = c->sym_rows_summed = false;
     c->acc_valid = false;
     return NBODY_OK;
 }
@@ -739,7 +740,7 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
                 HIP_TRY(c, hipMalloc((void **)&c->colparts_own, sizeof(float4) * (size_t)kSymGroups * (size_t)c->n_total));
             c->colparts = c->colparts_own;
         }
-        c->sym_reduced = false;
+        c->sym_reduced = c->sym_rows_summed = false;
     }
     c->force_mode = mode;
     std::fill(c->split_done.begin(), c->split_done.end(), 0);
@@ -762,7 +763,7 @@ int nbody_sym_set_colparts(nbody_ctx *c, float *d_buf)
         }
         c->colparts = c->colparts_own;
     }
-    c->sym_reduced = false;
+    c->sym_reduced = c->sym_rows_summed = false;
     return NBODY_OK;
 }
 
@@ -797,6 +798,29 @@ int nbody_sym_reduce(nbody_ctx *c)
     return NBODY_OK;
 }
 
+// The row-side sums of the last part's rows (every earlier part's were formed beside the tile launches).  They need this
+// context's own partial sums only, so a sharded host runs them while the column-side sums are on the wire:
+// forces -> nbody_sym_reduce -> [start the exchange] -> nbody_sym_rowsum -> [exchange lands] -> nbody_update.
+int nbody_sym_rowsum(nbody_ctx *c)
+{
+    if (!c || c->force_mode != NBODY_FORCE_SYMMETRIC)
+        return fail(c, NBODY_ERR_INVALID, "nbody_sym_rowsum: the context is not in the pair-once mode");
+    int rc = all_splits_done(c, "nbody_sym_rowsum");
+    if (rc != NBODY_OK)
+        return rc;
+    if (!c->pending)
+        return fail(c, NBODY_ERR_STATE, "nbody_sym_rowsum: no force call since the last update");
+    if (c->sym_rows_summed)
+        return NBODY_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const nbody_ctx::SymPart &p = *c->pending;
+    HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + p.row_off, c->rowsum + p.b0,
+                                 (int)(c->row_lo + p.b0), (int)p.rows, (int)c->split_len, c->n_splits, c->group_splits,
+                                 (int)c->row_count, c->stream));
+    c->sym_rows_summed = true;
+    return NBODY_OK;
+}
+
 // Pair-once mode: what is still missing of the group sums -- the column-side sums of the last part (unless nbody_sym_reduce
 // has run: a shard exchanges them first) and the row-side sums of its rows.  After it rowsum[g][b] and colparts[g][b] hold
 // every group's two halves for the context's rows.
@@ -810,12 +834,10 @@ static int sym_group_sums(nbody_ctx *c, const char *who)
         if (rc != NBODY_OK)
             return rc;
     }
-    HIP_TRY(c, hipSetDevice(c->device));
-    const nbody_ctx::SymPart &p = *c->pending;
-    HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + p.row_off, c->rowsum + p.b0,
-                                 (int)(c->row_lo + p.b0), (int)p.rows, (int)c->split_len, c->n_splits, c->group_splits,
-                                 (int)c->row_count, c->stream));
-    c->sym_reduced = false;
+    int rc = nbody_sym_rowsum(c);
+    if (rc != NBODY_OK)
+        return rc;
+    c->sym_reduced = c->sym_rows_summed = false;
     return NBODY_OK;
 }
 
@@ -1242,7 +1264,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         for (int s = 0; s < c->n_splits; ++s)
             if ((s >= first && s < first + count) != complement)
                 c->split_done[(size_t)s] = 1;
-        c->sym_reduced = false;
+        c->sym_reduced = c->sym_rows_summed = false;
         return NBODY_OK;
     }
     {
@@ -1591,8 +1613,9 @@ static int ensure_order_buffers(nbody_ctx *c, size_t tmp_bytes)
         HIP_TRY(c, hipMalloc((void **)&c->order_perm, sizeof(unsigned) * (size_t)c->n_total));
     const size_t need = order_scratch_bytes((int)c->n_total);
     if (need > c->order_scratch_bytes) {
-        if (c->order_scratch) {
+        if (c->order_scratch) {  // earlier order work may have been enqueued on either stream
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->own_stream));
             (void)hipFree(c->order_scratch);
         }
         c->order_scratch = nullptr;
@@ -1603,6 +1626,7 @@ static int ensure_order_buffers(nbody_ctx *c, size_t tmp_bytes)
     if (tmp_bytes > c->order_tmp_bytes) {
         if (c->order_tmp) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->own_stream));
             (void)hipFree(c->order_tmp);
         }
         c->order_tmp = nullptr;

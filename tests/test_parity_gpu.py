@@ -224,6 +224,9 @@ def test_reference_dataset_galaxy_20k_ten_steps(nb, oracle_mod, golden_dir, mode
     assert np.array_equal(v[:, 3], pvel[:, 3])          # the eps column the reference loads and never reads: preserved
 
 
+_DATASET_ORACLE = {}
+
+
 @pytest.mark.parametrize("mode", ["one_sided", "pair_once"])
 @pytest.mark.parametrize("name,frames", [("k17hp.snap", 10), ("k17c.snap", 3), ("stars_8192.dat", 1)])
 def test_reference_datasets_k17hp_and_stars(nb, oracle_mod, golden_dir, name, frames, mode):
@@ -238,12 +241,13 @@ def test_reference_datasets_k17hp_and_stars(nb, oracle_mod, golden_dir, name, fr
     <= 6.4e-7 / 3.0e-6."""
     import os
     from n_body_problem_amd import datasets as ds
-    pos, vel = ds.read_any(os.path.join(golden_dir, name))
-    assert pos.shape[0] == {"k17hp.snap": 10002, "k17c.snap": 32770, "stars_8192.dat": 8192}[name]
-    ppos, pvel = nb.pad_reference_style(pos, vel)
-    n = pos.shape[0]
-    p3, v3 = oracle_mod.step_v3(ppos, pvel, nsteps=frames)
-    p64, v64 = oracle_mod.step_f64(ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, nsteps=frames)
+    if name not in _DATASET_ORACLE:                              # the CPU paths once per session, not once per force mode
+        pos, vel = ds.read_any(os.path.join(golden_dir, name))
+        ppos, pvel = nb.pad_reference_style(pos, vel)
+        _DATASET_ORACLE[name] = (pos.shape[0], ppos, pvel, oracle_mod.step_v3(ppos, pvel, nsteps=frames),
+                                 oracle_mod.step_f64(ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, nsteps=frames))
+    n, ppos, pvel, (p3, v3), (p64, v64) = _DATASET_ORACLE[name]
+    assert n == {"k17hp.snap": 10002, "k17c.snap": 32770, "stars_8192.dat": 8192}[name]
     oracle_vs_truth = (rel_state_error(p3[:n], p64[:n]), rel_state_error(v3[:n], v64[:n]))
     for order in ("given", "morton"):
         p, v = run_gpu(nb, ppos, pvel, nb.TIME_TICK, nb.SOFTENING_VERSION3, frames, mode, body_order=order)
