@@ -79,6 +79,9 @@ struct nbody_ctx {
     hipStream_t aux_stream = nullptr;  // pair-once mode: the diagonal-tile launch runs here, beside the tile launch
     hipStream_t tile_stream2 = nullptr;  // NBODY_SYM_TILE_STREAMS=2 (experiment): odd summation parts' tiles, lowest priority
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_graph_in = nullptr, ev_graph_out = nullptr;
+    hipEvent_t ev_flags = nullptr;  // the step's equal-mass flags have been written (a later force call may run on another stream)
+    bool flags_valid = false;       // split_mass holds the flags of the positions of this step (launch_split_mass has run since the
+                                    // partial sums were last consumed or forgotten)
     float4 *partials = nullptr;    // [n_splits][row_count]  (the reference's gravity_sum_array, kernel.cu:1148);
                                    // pair-once mode: [n_splits / 2 + 1][row_count].  Allocated at the first force call.
     size_t partials_entries = 0;
@@ -114,6 +117,13 @@ static int fail(nbody_ctx *c, int status, const std::string &msg)
 }
 
 static void free_sym_tiles(nbody_ctx *c);
+
+// Partial sums consumed or forgotten: the next force call starts a new step (and recomputes the equal-mass flags).
+static void clear_split_done(nbody_ctx *c)
+{
+    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    c->flags_valid = false;
+}
 
 // The captured step bakes in every device pointer the launches take (partial sums, tile lists, exchange buffer): whatever
 // frees or replaces one of them drops the graph, and the next nbody_step_n captures a new one.
@@ -387,6 +397,7 @@ int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row
     guard(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate");
     guard(hipEventCreateWithFlags(&c->ev_graph_in, hipEventDisableTiming), "hipEventCreate");
     guard(hipEventCreateWithFlags(&c->ev_graph_out, hipEventDisableTiming), "hipEventCreate");
+    guard(hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming), "hipEventCreate");
     c->stream = c->own_stream;
     size_t red = (size_t)std::max(1, energy_blocks((int)row_count)) * 4;
     if (rc == NBODY_OK)
@@ -459,6 +470,7 @@ int nbody_destroy(nbody_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_graph_in) (void)hipEventDestroy(c->ev_graph_in);
     if (c->ev_graph_out) (void)hipEventDestroy(c->ev_graph_out);
+    if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
     if (c->tile_stream2) (void)hipStreamDestroy(c->tile_stream2);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -678,6 +690,7 @@ static int resplit(nbody_ctx *c, int64_t split_len)
     c->split_len = split_len;
     c->n_splits = (int)((c->n_total + split_len - 1) / split_len);
     c->split_done.assign((size_t)c->n_splits, 0);
+    c->flags_valid = false;
     if (c->split_mass) (void)hipFree(c->split_mass);
     c->split_mass = nullptr;
     HIP_TRY(c, hipMalloc((void **)&c->split_mass, sizeof(float) * (size_t)std::max(1, c->n_splits)));
@@ -743,7 +756,7 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         c->sym_reduced = c->sym_rows_summed = false;
     }
     c->force_mode = mode;
-    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    clear_split_done(c);
     c->acc_valid = false;
     drop_step_graph(c);
     return NBODY_OK;
@@ -895,6 +908,7 @@ int nbody_set_equal_mass_path(nbody_ctx *c, int on)
         return NBODY_ERR_INVALID;
     c->equal_mass_path = on != 0;
     c->acc_valid = false;
+    c->flags_valid = false;
     return NBODY_OK;
 }
 
@@ -919,7 +933,7 @@ int nbody_set_summation_parts(nbody_ctx *c, int parts)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
         free_sym_tiles(c);  // the cached plans carry the cut into parts
-        std::fill(c->split_done.begin(), c->split_done.end(), 0);
+        clear_split_done(c);
     }
     c->sum_parts = parts;
     c->acc_valid = false;
@@ -1199,7 +1213,15 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             sa.row_count = (int)p.rows;
         };
         HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, launch_split_mass(sa.pos, c->split_mass, sa.n_total, L, c->equal_mass_path, c->stream));
+        // the equal-mass flags once per step, by its first force call: a later call for other columns (the complement launch on
+        // a second stream, the ring's chunks) would rewrite the same values under the kernels that read them
+        if (!c->flags_valid) {
+            HIP_TRY(c, launch_split_mass(sa.pos, c->split_mass, sa.n_total, L, c->equal_mass_path, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_flags, c->stream));
+            c->flags_valid = true;
+        } else {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_flags, 0));  // written on the stream of the step's first call
+        }
         // The auxiliary stream, beside the tile launches: a part's diagonal tiles (pairs inside one split; their own slot of
         // the row-side array: 0.56 ms at N = 2^20 that no longer stands between the tiles and the summation), and, once the
         // part's tile launch is over, its column-side sums per group and the row-side sums of its rows.  With two slots the
@@ -1299,8 +1321,15 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
     const int rpl = pick_rows_per_lane(c, a.split_count);
     // the one-wave kernel forms the equal-mass flag of a one-tile split from the tile it holds: no launch in front
     a.own_split_mass = rpl == 41 && a.split_len == kTile && !a.eps_pp && c->equal_mass_path;
-    if (!a.own_split_mass)
-        HIP_TRY(c, launch_split_mass(a.pos, c->split_mass, a.n_total, a.split_len, c->equal_mass_path, c->stream));
+    if (!a.own_split_mass) {  // once per step, see the pair-once branch
+        if (!c->flags_valid) {
+            HIP_TRY(c, launch_split_mass(a.pos, c->split_mass, a.n_total, a.split_len, c->equal_mass_path, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_flags, c->stream));
+            c->flags_valid = true;
+        } else {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_flags, 0));
+        }
+    }
     {
         TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches);
         HIP_TRY(c, launch_forces(a, rpl, c->stream));
@@ -1351,7 +1380,7 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
                                      (int)c->row_lo, (int)c->row_count, n_splits, dt, c->stream));
         }
     }
-    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    clear_split_done(c);
     return NBODY_OK;
 }
 
@@ -1389,7 +1418,7 @@ int nbody_invalidate_forces(nbody_ctx *c)
     if (!c)
         return NBODY_ERR_INVALID;
     c->acc_valid = false;
-    std::fill(c->split_done.begin(), c->split_done.end(), 0);  // partial sums of other positions are no partial sums
+    clear_split_done(c);  // partial sums of other positions are no partial sums
     return NBODY_OK;
 }
 
@@ -1410,7 +1439,7 @@ int nbody_kdk_prepare(nbody_ctx *c)
         return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_kdk_reduce(c->acc, partials, (int)c->row_count, n_splits, c->stream));
-    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    clear_split_done(c);
     c->acc_valid = true;
     return NBODY_OK;
 }
@@ -1459,7 +1488,7 @@ int nbody_kdk_kick(nbody_ctx *c, float *d_vel, float dt)
         HIP_TRY(c, launch_kdk_kick(reinterpret_cast<float4 *>(d_vel), c->acc, partials, (int)c->row_count, n_splits, dt,
                                    c->stream));
     }
-    std::fill(c->split_done.begin(), c->split_done.end(), 0);
+    clear_split_done(c);
     c->acc_valid = true;
     return NBODY_OK;
 }
