@@ -57,4 +57,26 @@ for L in args.split_len:
             best = min(best, ev[0].elapsed_time(ev[1]))
     print(f"N={n} rank {args.rank}/{args.world} mode={args.mode} split_len={L} two_streams={args.two_streams} morton={args.morton}: "
           f"{best:.3f} ms per step share -> x{args.world} ranks = {float(n) * n / best / 1e9:.3f}e12 interactions/s")
+    if args.morton:
+        # one rank's share of a layout refresh (nbody_multi_reorder without the wire): the permutation from the rank's own replica,
+        # the replica gathered in place, the rank's velocity rows gathered out of all rows, the order array composed
+        import ctypes
+        from n_body_problem_amd._lib import check
+        lib, ptr = s._lib, (lambda t: ctypes.c_void_p(t.data_ptr()))
+        vel_all = torch.from_numpy(vel).cuda()
+        order = torch.arange(n, dtype=torch.int64, device="cuda")
+        refresh = 1e9
+        for it in range(4):
+            torch.cuda.synchronize()
+            ev[0].record()
+            s._use_current_stream()
+            check(lib.nbody_order_compute(s._ctx, ptr(s.positions), n, ptr(order)), s._ctx)
+            check(lib.nbody_order_gather(s._ctx, ptr(s.positions), ptr(s.positions), 0, n, 4), s._ctx)
+            check(lib.nbody_order_gather(s._ctx, ptr(s.velocities), ptr(vel_all), lo, chunk, 4), s._ctx)
+            check(lib.nbody_order_gather(s._ctx, ptr(order), ptr(order), 0, n, 2), s._ctx)
+            ev[1].record()
+            torch.cuda.synchronize()
+            if it:
+                refresh = min(refresh, ev[0].elapsed_time(ev[1]))
+        print(f"    one rank's share of a layout refresh: {refresh:.3f} ms = {100 * refresh / (50 * best):.3f} % of 50 steps of {best:.3f} ms")
     s.close()
