@@ -231,17 +231,17 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
  *     nbody_update / nbody_kdk_*                (adds row-side and column-side sums in the fixed order)
  * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
 /* NBODY_FORCE_AUTO (nbody_set_force_mode only; a context that owns every row, nothing pending): the pair-once mode from
- * NBODY_PAIR_ONCE_MIN_BODIES bodies on -- where it delivers more interactions per second (N = 65 536: 0.77 against 0.95 ms
- * per step; N = 2^20: 150 against 229 ms) -- the one-sided mode below, where the pair-once grid is too coarse to fill the
- * chip (N = 20 225: 0.18 against 0.15 ms), and the context's split length is changed to the one that mode wants
+ * NBODY_PAIR_ONCE_MIN_BODIES bodies on -- where it delivers more interactions per second (profiles/r03_mode_crossover.txt:
+ * N = 32 768: 0.229 against 0.251 ms per step, 65 536: 0.71 against 0.94, 2^20: 150 against 229) -- the one-sided mode below,
+ * where the pair-once grid is too coarse to fill the chip (N = 24 576: 0.164 against 0.148 ms, 20 225: 0.18 against 0.12), and the context's split length is changed to the one that mode wants
  * (nbody_pair_once_split_len / nbody_default_split_len).  nbody_force_mode reads the mode in use. */
-#define NBODY_PAIR_ONCE_MIN_BODIES 65536
+#define NBODY_PAIR_ONCE_MIN_BODIES 32768
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1, NBODY_FORCE_AUTO = 2 };
 int nbody_force_mode(const nbody_ctx *ctx);
 /* The split length to create a pair-once context with.  A function of n_total ONLY (split boundaries define the
- * summation order, so they must not depend on the sharding): 1024 from 204 800 bodies up -- the kernel's rows per
- * pass, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles below that (small systems
- * need more, smaller tiles to fill the chip), 2048 from N = 2^20 (half the partial sums: 2.2 % faster at equal memory)
+ * summation order, so they must not depend on the sharding): 1024 from 153 600 bodies up -- whole passes of the eight-row
+ * loops, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles (256 or 512) below that
+ * (small systems need more, smaller tiles to fill the chip), 2048 from N = 2^20 (half the partial sums: 2.2 % faster at equal memory)
  * and 4096 from 2^23, so that the partial sums of one pass (n_total^2 / split_len entries of 12 bytes over all contexts:
  * 6.4 GB at N = 2^20, 103 GB at N = 2^22) would still fit one GPU even in one summation part
  * (nbody_set_summation_parts; by default a single context holds 4.8 GB and 26 GB of them). */

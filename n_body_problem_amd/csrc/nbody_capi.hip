@@ -191,9 +191,13 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
     // summation order.
     // Below ~200 000 bodies 1024-body tiles are too few to fill 256 CUs x 5 workgroups evenly (N = 131072: 2016 tiles):
     // the splits shrink to n_total / 200, in whole 256-body tiles, and the tile kernel runs with 2 or 1 wave per workgroup.
+    // 768 (N = 153 600 ... 204 799 by that rule) is no length for the tile kernels: two waves cover 512 rows per pass, the
+    // second pass of a 768-body split runs half empty and the equal-mass loops are off where a pass is partial -- 8.88 ms per
+    // step at N = 196 608 against 8.48 for the one-sided mode, where N = 131 072 and 262 144 run at 0.71 of it
+    // (profiles/r03_mode_crossover.txt): from 153 600 bodies on the splits are 1024 bodies.
     const double pairs16 = 16.0 * (double)n_total * (double)n_total;
     int64_t len = n_total / 200 / kTile * kTile;
-    if (len < 1024)
+    if (len < 768)
         return len < kTile ? kTile : len;
     len = n_total >= ((int64_t)1 << 20) ? 2048 : 1024;
     while (len < 4096 && pairs16 / (double)len > 150e9)
