@@ -19,4 +19,6 @@ for n in sizes:
             s.step_n(K, 1e-3, 1e-2)
             torch.cuda.synchronize()
             out.append((time.perf_counter() - t0) / K * 1e3)
-    print(f"N={n:7d}  one_sided {out[0]:8.4f} ms  pair_once {out[1]:8.4f} ms  ratio {out[1] / out[0]:.3f}", flush=True)
+    frac = [20.0 * float(n) * n / (1.0 if m == 0 else 2.0) / (t * 1e-3) / 157.3e12 for m, t in enumerate(out)]
+    print(f"N={n:7d}  one_sided {out[0]:8.4f} ms  pair_once {out[1]:8.4f} ms  ratio {out[1] / out[0]:.3f}   whole-step fraction of the "
+          f"fp32 peak (20 flop x executed evaluations): {frac[0]:.3f} / {frac[1]:.3f}", flush=True)
