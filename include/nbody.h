@@ -239,9 +239,9 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1, NBODY_FORCE_AUTO = 2 };
 int nbody_force_mode(const nbody_ctx *ctx);
 /* The split length to create a pair-once context with.  A function of n_total ONLY (split boundaries define the
- * summation order, so they must not depend on the sharding): 1024 from 153 600 bodies up -- whole passes of the eight-row
- * loops, the finest grid that keeps every wave busy -- n_total / 200 in whole 256-body tiles (256 or 512) below that
- * (small systems need more, smaller tiles to fill the chip), 2048 from N = 2^20 (half the partial sums: 2.2 % faster at equal memory)
+ * summation order, so they must not depend on the sharding): 1024 from 131 072 bodies up -- whole passes of the eight-row
+ * loops, the finest grid that keeps every wave busy -- 512 from 65 536 and 256 below that (small systems need more, smaller
+ * tiles to fill the chip: measured per size, profiles/r03_split_len_mid_range.txt), 2048 from N = 2^20 (half the partial sums: 2.2 % faster at equal memory)
  * and 4096 from 2^23, so that the partial sums of one pass (n_total^2 / split_len entries of 12 bytes over all contexts:
  * 6.4 GB at N = 2^20, 103 GB at N = 2^22) would still fit one GPU even in one summation part
  * (nbody_set_summation_parts; by default a single context holds 4.8 GB and 26 GB of them). */

@@ -189,16 +189,18 @@ int64_t nbody_pair_once_split_len(int64_t n_total)
     // The length doubles again where 16-byte entries (round 1's layout: the bound is kept) would pass 150 GB: 4096 from
     // N = 2^23 (N = 2^22: 2048, 103 GB per pass, 26 GB held).  A function of n_total only: split boundaries define the
     // summation order.
-    // Below ~200 000 bodies 1024-body tiles are too few to fill 256 CUs x 5 workgroups evenly (N = 131072: 2016 tiles):
-    // the splits shrink to n_total / 200, in whole 256-body tiles, and the tile kernel runs with 2 or 1 wave per workgroup.
-    // 768 (N = 153 600 ... 204 799 by that rule) is no length for the tile kernels: two waves cover 512 rows per pass, the
-    // second pass of a 768-body split runs half empty and the equal-mass loops are off where a pass is partial -- 8.88 ms per
-    // step at N = 196 608 against 8.48 for the one-sided mode, where N = 131 072 and 262 144 run at 0.71 of it
-    // (profiles/r03_mode_crossover.txt): from 153 600 bodies on the splits are 1024 bodies.
+    // Below that the splits shrink with the system (more, smaller tiles to fill the chip; one or two waves per workgroup):
+    // 256 bodies up to 65 535, 512 up to 131 071 -- measured per size with the round-3 kernels, one GPU
+    // (profiles/r03_split_len_mid_range.txt: N = 49 152: 0.436 / 0.479 / 0.544 ms per step with 256 / 512 / 1024; 65 536:
+    // 0.722 / 0.715 / 0.840; 98 304: 1.582 / 1.524 / 1.591; 131 072: 2.79 / 2.66 / 2.62).  768 is no length for the tile
+    // kernels (two waves cover 512 rows per pass: the second pass would run half empty and the equal-mass loops are off
+    // where a pass is partial -- N = 196 608 ran at 8.88 ms per step with it, 5.79 with 1024).
     const double pairs16 = 16.0 * (double)n_total * (double)n_total;
-    int64_t len = n_total / 200 / kTile * kTile;
-    if (len < 768)
-        return len < kTile ? kTile : len;
+    if (n_total < 65536)
+        return kTile;
+    if (n_total < 131072)
+        return 2 * kTile;
+    int64_t len;
     len = n_total >= ((int64_t)1 << 20) ? 2048 : 1024;
     while (len < 4096 && pairs16 / (double)len > 150e9)
         len *= 2;

@@ -53,8 +53,8 @@ def test_default_split_len_is_tile_aligned_and_sharding_independent(lib):
 
 def test_pair_once_split_len_depends_on_the_body_count_only(lib):
     f = lib.nbody_pair_once_split_len
-    assert [f(n) for n in (0, 1, 20000, 65536, 1 << 17, 153599)] == [256, 256, 256, 256, 512, 512]   # small systems: finer tiles
-    assert [f(n) for n in (153600, 200000, 204800, 1 << 18, (1 << 20) - 1)] == [1024] * 5   # whole passes of the eight-row loops
+    assert [f(n) for n in (0, 1, 20000, 65535, 65536, 98304, (1 << 17) - 1)] == [256, 256, 256, 256, 512, 512, 512]   # small systems: finer tiles
+    assert [f(n) for n in (1 << 17, 153600, 200000, 1 << 18, (1 << 20) - 1)] == [1024] * 5   # whole passes of the eight-row loops
     assert [f(n) for n in (1 << 20, 1 << 21)] == [2048] * 2                           # half the partial sums, 2 % faster
     assert f(1 << 22) == 2048 and f(1 << 23) == 4096 and f(1 << 24) == 4096         # then bounded partial sums
     for n in (1 << 20, 1 << 21, 1 << 22):
