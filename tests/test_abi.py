@@ -96,3 +96,53 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
                 assert "nbody_oracle" not in text, f
+
+
+def test_header_is_plain_c_and_the_integration_patch_compiles(tmp_path):
+    """include/nbody.h must be usable from C (the boundary is a C ABI: no C++ in the header), and the call-site patch of
+    INTEGRATION.md section 2 -- the functions a maintainer of the reference would write -- must compile and link against the
+    library as written there."""
+    import subprocess
+    from n_body_problem_amd import build
+    build.build_library()
+    src = tmp_path / "patch.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "nbody.h"
+#define TIME_TICK 0.008
+typedef float real;
+static nbody_ctx* g_nbody = NULL;
+static int m_numBodies, m_initialized;
+void initialize(int numBodies) {
+    m_numBodies = numBodies;
+    if (nbody_create_auto(&g_nbody, /*device*/0, numBodies) != NBODY_OK) {
+        fprintf(stderr, "nbody_create_auto: %s\n", nbody_last_error(NULL));
+        exit(3);
+    }
+    m_initialized = 1;
+}
+void setParticlesPosition(real* data) { if (m_initialized) nbody_set_positions(g_nbody, data); }
+void setParticlesVelocity(real* data) { if (m_initialized) nbody_set_velocities(g_nbody, data); }
+int frame(void) {
+    int rc = nbody_step(g_nbody, nbody_positions_device(g_nbody), nbody_velocities_device(g_nbody),
+                        NULL, (float)TIME_TICK, 1.0e-2f);
+    if (rc != NBODY_OK) printf("nbody_step: %s\n", nbody_last_error(g_nbody));
+    return rc;
+}
+int main(void) {
+    nbody_multi_config cfg = {0};
+    cfg.n_bodies = 1024; cfg.force_mode = NBODY_FORCE_AUTO; cfg.body_order = NBODY_ORDER_MORTON;
+    printf("abi %d, split %lld, pair-once from %d bodies, cfg %lld\n", nbody_abi_version(),
+           (long long)nbody_pair_once_split_len(1 << 20), NBODY_PAIR_ONCE_MIN_BODIES, (long long)cfg.n_bodies);
+    return nbody_abi_version() == NBODY_ABI_VERSION ? 0 : 1;
+}
+''')
+    exe = tmp_path / "patch"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), str(src),
+           "-L" + os.path.join(ROOT, "n_body_problem_amd"), "-lnbody_amd", "-L/opt/rocm/lib",
+           "-Wl,-rpath," + os.path.join(ROOT, "n_body_problem_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)          # no device needed: only host helpers are called
+    assert run.returncode == 0 and "abi 4, split 2048, pair-once from 32768 bodies" in run.stdout, run.stdout + run.stderr
