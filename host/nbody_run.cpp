@@ -150,11 +150,17 @@ int main(int argc, char **argv)
                 }
             }
             const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            auto tm = ms.readTiming();
             const double inter = (double)b.n() * (double)b.n() * (double)steps;
-            std::printf("%lld steps in %.3f s: %.3f ms/step, %.3e interactions/s (rank 0: force kernels %.3f ms/step, update %.3f ms/step); "
-                        "replicas identical: %s\n", (long long)steps, wall, 1e3 * wall / (double)steps, inter / wall,
-                        tm.forceMs / (double)steps, tm.updateMs / (double)steps, ms.replicasIdentical() ? "yes" : "NO");
+            std::printf("%lld steps in %.3f s: %.3f ms/step, %.3e interactions/s; replicas identical: %s\n", (long long)steps, wall,
+                        1e3 * wall / (double)steps, inter / wall, ms.replicasIdentical() ? "yes" : "NO");
+            for (int i = 0; i < (int)inf[5]; ++i) {  // where every local rank's step went (library event totals, ms per step)
+                const auto t = ms.readRankTiming(i);
+                const double k = (double)std::max<std::int64_t>(1, t.steps);
+                std::printf("  rank %d: force kernels %.3f  behind them %.3f  position exchange %.3f on the wire, %.3f as the waiting "
+                            "launch saw it  column sums %.3f  host enqueue %.3f  layout refreshes %lld (%.3f ms each)\n", i,
+                            t.forceMs / k, t.updateMs / k, t.posExchangeCommMs / k, t.posExchangeWaitMs / k, t.columnSumExchangeMs / k,
+                            t.hostEnqueueMs / k, (long long)t.reorders, t.reorders ? t.reorderMs / (double)t.reorders : 0.0);
+            }
             if (!final_path.empty()) {
                 ms.download(b.pos.data(), b.vel.data());
                 save(final_path, step0 + steps, time0 + (double)steps * dt);

@@ -188,18 +188,26 @@ public:
         check(nbody_multi_replica_checksums(m_, c), "nbody_multi_replica_checksums");
         return c[0] == c[1];
     }
-    void timing(bool on)
+    // kernels of the shard contexts and the exchanges (nbody_multi_timing_*: HIP events on the streams they run on)
+    void timing(bool on) { check(nbody_multi_timing_enable(m_, on ? 1 : 0), "nbody_multi_timing_enable"); }
+    // Totals of one local rank since the last read (sums of event-pair durations, ms): where its steps went.
+    struct RankTiming {
+        std::int64_t steps;
+        double hostEnqueueMs, forceMs, updateMs, auxMs, posExchangeCommMs, posExchangeWaitMs, columnSumExchangeMs, reorderMs;
+        std::int64_t forceLaunches, updateLaunches, reorders;
+    };
+    RankTiming readRankTiming(int localIndex)
     {
-        for (int i = 0; nbody_multi_shard(m_, i); ++i)
-            nbody_timing_enable(nbody_multi_shard(m_, i), on ? 1 : 0);
+        double v[16];
+        check(nbody_multi_timing_read(m_, localIndex, v), "nbody_multi_timing_read");
+        return {(std::int64_t)v[0], v[1], v[2], v[4], v[6], v[8], v[10], v[12], v[14],
+                (std::int64_t)v[3], (std::int64_t)v[5], (std::int64_t)v[15]};
     }
-    // sums of per-launch durations of local rank 0's kernels since the last read
+    // local rank 0's kernels, in the shape of System::readTiming
     System::Timing readTiming()
     {
-        System::Timing t{};
-        if (nbody_timing_read(nbody_multi_shard(m_, 0), &t.forceMs, &t.forceLaunches, &t.updateMs, &t.updateLaunches) != NBODY_OK)
-            throw std::runtime_error("nbody_timing_read failed");
-        return t;
+        const RankTiming r = readRankTiming(0);
+        return {r.forceMs, r.updateMs, r.forceLaunches, r.updateLaunches};
     }
     std::vector<std::int64_t> info()
     {
