@@ -1367,7 +1367,20 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
     HIP_TRY(c, hipSetDevice(c->device));
     {
         TimedLaunch t(c, &c->ev_update, &c->update_ms, &c->update_launches);
-        if (c->force_mode == NBODY_FORCE_SYMMETRIC) {  // the combination of the group sums rides in the update kernel
+        // Small and mid-size systems (every row, the tiles in one part, nothing summed yet): one finishing kernel instead of
+        // column sums + row sums + update.  NBODY_SYM_FUSED_FINISH=0 switches it off, =N sets the largest split count it
+        // is used for (A/B measurement; the bits are the same either way).
+        static const int fused_max_splits = getenv("NBODY_SYM_FUSED_FINISH") ? atoi(getenv("NBODY_SYM_FUSED_FINISH")) : 320;
+        if (c->force_mode == NBODY_FORCE_SYMMETRIC && c->row_lo == 0 && c->row_count == c->n_total && c->pending &&
+            !c->sym_reduced && !c->sym_rows_summed && c->pending->g1 - c->pending->g0 == c->group_count &&
+            c->pending->row_off == 0 && c->pending->col_off == 0 && c->n_splits <= fused_max_splits) {
+            int rc = all_splits_done(c, "nbody_update");
+            if (rc != NBODY_OK)
+                return rc;
+            HIP_TRY(c, launch_sym_finish_update(reinterpret_cast<const float3 *>(c->partials), c->col_partials,
+                                                reinterpret_cast<float4 *>(d_pos), reinterpret_cast<float4 *>(d_vel), (int)c->n_total,
+                                                (int)c->split_len, c->n_splits, c->group_splits, dt, c->stream));
+        } else if (c->force_mode == NBODY_FORCE_SYMMETRIC) {  // the combination of the group sums rides in the update kernel
             int rc = all_splits_done(c, "nbody_update");
             if (rc == NBODY_OK)
                 rc = sym_group_sums(c, "nbody_update");

@@ -98,6 +98,11 @@ hipError_t launch_sym_rowsum(const float3 *row_partials, float4 *rowsum, int row
 hipError_t launch_sym_combine(const float4 *rowsum, const float4 *colparts, float4 *acc, int row_lo, int row_count, int n_total,
                               int n_groups, hipStream_t stream);
 
+// A context that owns every row, tiles in one part: column sums + row sums + combination + kick-drift in one launch (the same
+// association as the three kernels above).
+hipError_t launch_sym_finish_update(const float3 *row_partials, const float3 *col_partials, float4 *pos_all, float4 *vel_rows,
+                                    int n_total, int split_len, int n_splits, int group_splits, float dt, hipStream_t stream);
+
 // Partial accelerations of rows [row_lo,row_lo+row_count) from splits [split_first, split_first+split_count).
 // rows_per_lane in {1,2,4,8}.  eps2 == 0 selects the zero-distance-guarded variant.
 hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stream);

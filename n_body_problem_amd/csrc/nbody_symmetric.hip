@@ -1126,6 +1126,77 @@ __global__ __launch_bounds__(kTile) void sym_combine_kernel(const float4 *rowsum
     acc[b] = make_float4(ax, ay, az, 0.f);
 }
 
+// ---- one finishing kernel for small and mid-size systems (round 3) ----------------------------------------------------------
+// A context that owns every row and ran its tiles in ONE part: sym_colparts_kernel's sum, sym_rowsum_kernel's sum, their
+// combination and the kick-drift of update_kernel in one launch instead of three -- one lane per (body, group), the eight
+// group values of a body combined in ascending order through LDS: the same sums in the same association, not a bit changes.
+// At N = 32 768 the tile kernel takes 185 us of a 234 us step and the rest is small launches (profiles/r03_mid_range_kernel_stats.txt).
+__global__ __launch_bounds__(256) void sym_finish_update_kernel(const float3 *row_partials, const float3 *col_partials,
+                                                                float4 *pos_all, float4 *vel_rows, int n_total, int split_len,
+                                                                int n_splits, int group_splits, int n_groups, float dt)
+{
+    __shared__ float part[kSymGroups][32][3];
+    const int bl = threadIdx.x & 31, g = threadIdx.x >> 5;  // 32 consecutive bodies per group: 384 contiguous bytes per load
+    const int b = blockIdx.x * 32 + bl;
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if (b < n_total && g < n_groups) {
+        const int B = b / split_len, off = b - B * split_len;
+        const int s0 = g * group_splits, s1 = min(s0 + group_splits, n_splits);
+        float cx = 0.f, cy = 0.f, cz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
+        for (int R = s0; R < s1; ++R)  // column side: body b as a column of the tiles (R, B), R in group g
+            if (sym_rows_side(R, B, n_splits)) {
+                const float3 v = sym_col_slot(const_cast<float3 *>(col_partials), R, sym_distance(R, B, n_splits), n_splits, split_len)[off];
+                cx += v.x;
+                cy += v.y;
+                cz += v.z;
+            }
+        for (int C = s0; C < s1; ++C)  // row side: body b as a row of the tiles (B, C), C in group g, and of the diagonal tile
+            if (C == B || sym_rows_side(B, C, n_splits)) {
+                const float3 v = row_partials[(size_t)sym_distance(B, C, n_splits) * n_total + b];
+                rx += v.x;
+                ry += v.y;
+                rz += v.z;
+            }
+        vx = rx + cx;  // sym_combine_kernel: rs + cp, then into the running sum
+        vy = ry + cy;
+        vz = rz + cz;
+    }
+    part[g][bl][0] = vx;
+    part[g][bl][1] = vy;
+    part[g][bl][2] = vz;
+    __syncthreads();
+    if (g != 0 || b >= n_total)
+        return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < n_groups; ++k) {
+        ax += part[k][bl][0];
+        ay += part[k][bl][1];
+        az += part[k][bl][2];
+    }
+    float4 v = vel_rows[b];
+    float4 x = pos_all[b];
+    const double h = (double)dt;
+    v.x = (float)__builtin_fma((double)ax, h, (double)v.x);
+    v.y = (float)__builtin_fma((double)ay, h, (double)v.y);
+    v.z = (float)__builtin_fma((double)az, h, (double)v.z);
+    x.x = (float)__builtin_fma((double)v.x, h, (double)x.x);
+    x.y = (float)__builtin_fma((double)v.y, h, (double)x.y);
+    x.z = (float)__builtin_fma((double)v.z, h, (double)x.z);
+    vel_rows[b] = v;
+    pos_all[b] = x;
+}
+
+hipError_t launch_sym_finish_update(const float3 *row_partials, const float3 *col_partials, float4 *pos_all, float4 *vel_rows,
+                                    int n_total, int split_len, int n_splits, int group_splits, float dt, hipStream_t stream)
+{
+    if (n_total <= 0)
+        return hipSuccess;
+    const int n_groups = (n_splits + group_splits - 1) / group_splits;
+    hipLaunchKernelGGL(sym_finish_update_kernel, dim3((n_total + 31) / 32), dim3(256), 0, stream, row_partials, col_partials, pos_all,
+                       vel_rows, n_total, split_len, n_splits, group_splits, n_groups, dt);
+    return hipGetLastError();
+}
+
 hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int n_total, int split_len, int n_splits,
                                int split_lo, int group_splits, int group_lo, int group_count, hipStream_t stream)
 {
