@@ -388,6 +388,69 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
+// ---- EIGHT rows per lane with PER-PARTICLE SOFTENING (round 3): eps_ij^2 = eps^2 + eps_i^2 + eps_j^2 (the eps the
+// reference loads into vel.w, kernel.cu:223, and never reads).  S9 plus one packed add per (row, column pair): the column
+// pair's eps_j^2 (staged per wave, read with the positions) plus the row's eps^2 + eps_i^2 becomes the first addend of the
+// r^2 chain -- the order of force_sym_general_kernel: fma(dx, dx, (eps^2 + eps_i^2) + eps_j^2).  8.5 packed instructions + 1
+// transcendental per pair; its own kernel instantiation (ROWS8 = 3), used for splits of whole 1024 bodies and eps > 0 (a
+// particle may have eps_i = 0: with eps = 0 the guarded compiler-scheduled kernel keeps running).
+//   EC = v[134:135] (class 1) the column pair's eps_j^2, read through v146 (its own staging array, the 64 columns twice)
+//   row terms (e0,e1) v[132:133]  (e2,e3) v[136:137]  (e4,e5) v[140:141]  (e6,e7) v[144:145]  (class 0), e_k = eps^2 + eps_k^2
+#define S10_PRE2(RXYA, RXYB, RZZ, ER)                                                                            \
+    "v_pk_add_f32 v[30:31], v[2:3], " RXYA " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                   \
+    "v_pk_add_f32 v[42:43], v[2:3], " RXYB " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                   \
+    "v_pk_add_f32 v[34:35], v[6:7], " RXYA " op_sel:[0,1] op_sel_hi:[1,1]" S2_NEG                                   \
+    "v_pk_add_f32 v[46:47], v[6:7], " RXYB " op_sel:[0,1] op_sel_hi:[1,1]" S2_NEG                                   \
+    "v_pk_add_f32 v[38:39], v[4:5], " RZZ S8_ZLO S2_NEG                                                             \
+    "v_pk_add_f32 v[50:51], v[4:5], " RZZ S8_ZHI S2_NEG                                                             \
+    "v_pk_add_f32 v[28:29], v[134:135], " ER " op_sel:[0,0] op_sel_hi:[1,0]\n\t"                                     \
+    "v_pk_add_f32 v[32:33], v[134:135], " ER " op_sel:[0,1] op_sel_hi:[1,1]\n\t"                                     \
+    "v_pk_fma_f32 v[28:29], v[30:31], v[30:31], v[28:29]\n\tv_pk_fma_f32 v[32:33], v[42:43], v[42:43], v[32:33]\n\t" \
+    "v_pk_fma_f32 v[28:29], v[34:35], v[34:35], v[28:29]\n\tv_pk_fma_f32 v[32:33], v[46:47], v[46:47], v[32:33]\n\t" \
+    "v_pk_fma_f32 v[28:29], v[38:39], v[38:39], v[28:29]\n\tv_pk_fma_f32 v[32:33], v[50:51], v[50:51], v[32:33]\n\t"
+#define S10_EPS(E0, E1) "ds_read2_b32 v[134:135], v146 offset0:" E0 " offset1:" E1 "\n\t"
+#define S10_ADVANCE S2_ADVANCE "v_add_u32_e32 v146, 16, v146\n\t"
+#define S10_STEP(NEXT, NEXT_MASSES)                                                                              \
+    "s_waitcnt lgkmcnt(7)\n\t" /* positions and eps_j^2 of the column pair have arrived (masses, permutes may be in flight) */ \
+    S10_PRE2("v[12:13]", "v[16:17]", "v[14:15]", "v[132:133]")                                                   \
+    S8_RSQ NB_SYM_GAP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    NB_SYM_PRIO_POST                                                                                             \
+    S9_POST2("v[64:65]", "v[66:67]", "v[68:69]", "v[70:71]", "v[72:73]", "v[74:75]", "v[118:119]")               \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S10_PRE2("v[20:21]", "v[24:25]", "v[18:19]", "v[136:137]")                                                   \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S9_POST2("v[76:77]", "v[78:79]", "v[80:81]", "v[82:83]", "v[84:85]", "v[86:87]", "v[122:123]")               \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S10_PRE2("v[48:49]", "v[52:53]", "v[22:23]", "v[140:141]")                                                   \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S9_POST2("v[88:89]", "v[90:91]", "v[92:93]", "v[94:95]", "v[96:97]", "v[98:99]", "v[126:127]")               \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S10_PRE2("v[56:57]", "v[60:61]", "v[26:27]", "v[144:145]")                                                   \
+    NEXT /* the next step's positions and eps_j^2 */                                                             \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S9_POST2("v[100:101]", "v[102:103]", "v[104:105]", "v[106:107]", "v[108:109]", "v[110:111]", "v[130:131]")   \
+    NB_SYM_PRIO_PRE                                                                                              \
+    NEXT_MASSES                                                                                                  \
+    S8_ROTATE
+#define S10_GROUP_LOOP                                                                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    S2_READ("0", "32", "128", "160") S10_EPS("0", "32")                                                          \
+    S9_MASSES("128", "160")                                                                                      \
+    S8_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 8\n"                                                                                      \
+    "1:\n\t"                                                                                                     \
+    S10_STEP(S2_READ("1", "33", "129", "161") S10_EPS("1", "33"), S9_MASSES("129", "161"))                       \
+    S10_STEP(S2_READ("2", "34", "130", "162") S10_EPS("2", "34"), S9_MASSES("130", "162"))                       \
+    S10_STEP(S2_READ("3", "35", "131", "163") S10_EPS("3", "35"), S9_MASSES("131", "163"))                       \
+    S10_STEP(S10_ADVANCE S2_READ("0", "32", "128", "160") S10_EPS("0", "32"), S9_MASSES("128", "160"))           \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"
+
 // ---- the same two-columns-per-step loop for tiles with arbitrary masses: 8 packed instructions + 1 transcendental per pair
 // (one-column loop: 16 + 1).  The group's masses are staged as a fourth array m[128] behind x, y, z and read at the END of
 // a step (the positions are consumed by the PRE blocks, the masses by the POST blocks of both batches).
@@ -483,12 +546,13 @@ __device__ __forceinline__ int sym_group(int g, int wave, int spacing, int G)
 // ---- off-diagonal tiles (I < J) ------------------------------------------------------------------------------
 typedef float nb_f16 __attribute__((ext_vector_type(16)));
 // ROWS8 = 1: equal-mass tiles through the eight-rows-per-lane loop (<= 128 VGPRs: four waves per SIMD), the others through
-// the four-row loops; 2: the eight-row loops for both kinds of tile (S9_GROUP_LOOP needs ~150 VGPRs: three waves per SIMD)
+// the four-row loops; 2: the eight-row loops for both kinds of tile (S9_GROUP_LOOP needs ~150 VGPRs: three waves per SIMD);
+// 3: every tile through S10_GROUP_LOOP (per-particle softening, ~160 VGPRs: three waves per SIMD)
 #ifndef NB_S8_WAVES
 #define NB_S8_WAVES 4  /* waves per SIMD the eight-row equal-mass kernel is allocated for */
 #endif
 template <int W, bool GUARD, int ROWS8 = 0>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 == 2 ? 3 : ROWS8 == 1 ? NB_S8_WAVES : 5))) void force_sym_kernel(SymArgs a)  // ROWS8 = 0: <= 96 VGPRs
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 >= 2 ? 3 : ROWS8 == 1 ? NB_S8_WAVES : 5))) void force_sym_kernel(SymArgs a)  // ROWS8 = 0: <= 96 VGPRs
 {
     constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -504,7 +568,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
     const float mass_rows = GUARD ? __builtin_nanf("") : a.split_mass[t.x], mass_cols = GUARD ? mass_rows : a.split_mass[t.y];
     // ... and only when every pass is full: the lanes of a partial last pass (split lengths that are not a multiple of the
     // rows per pass, e.g. 768 with two waves) carry dummy rows whose zero MASS is what keeps them out of the column sums
-    const bool uniform = !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;
+    const bool uniform = ROWS8 != 3 && !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;  // 3: masses in the loop
     const float row_scale = uniform ? mass_cols : 1.f, col_scale = uniform ? mass_rows : 1.f;
 
     for (int c = tid; c < L; c += kSymThreads)
@@ -662,7 +726,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
     };
     // eight rows per lane (S8_GROUP_LOOP: equal-mass tiles; S9_GROUP_LOOP: arbitrary masses): a wave owns 512 rows of a pass
     auto passes8 = [&](auto general_tag) {
-        constexpr bool GENERAL = decltype(general_tag)::value;
+        constexpr int VARIANT8 = decltype(general_tag)::value;  // 0: equal-mass tile (S8), 1: arbitrary masses (S9), 2: + per-particle softening (S10)
+        constexpr bool GENERAL = VARIANT8 >= 1, PPS8 = VARIANT8 == 2;
+        float *estage8 = lds.sz + L + wave * 128;  // PPS8: the group's eps_j^2, the 64 columns twice
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         // Which of the 64 bodies of a row block / column group a lane holds: 4 (lane mod 16) + lane / 16, so that the four
         // lanes one ALU lane serves in consecutive cycles (l, l + 16, l + 32, l + 48) hold four CONSECUTIVE bodies -- with the
@@ -671,23 +737,34 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
         const int sl = 4 * (lane & 15) + (lane >> 4);
         for (int pass0 = 0; pass0 < L; pass0 += kSymThreads * 8) {
             float4 p[8];
+            float er[8];  // PPS8: eps^2 + eps_i^2 of the rows
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int r = pass0 + (wave * 8 + k) * 64 + sl;
                 p[k] = zero4;
-                if (r < L && rowbase + r < row_hi)
+                float e = 0.f;
+                if (r < L && rowbase + r < row_hi) {
                     p[k] = a.pos[rowbase + r];
+                    if (PPS8)
+                        e = a.eps_pp[rowbase + r];
+                }
+                er[k] = __builtin_fmaf(e, e, a.eps2);
             }
+            const nb_f2 e01 = {er[0], er[1]}, e23 = {er[2], er[3]}, e45 = {er[4], er[5]}, e67 = {er[6], er[7]};
             const nb_f16 rows = {p[0].x, p[0].y, p[0].z, p[1].z, p[1].x, p[1].y, p[2].z, p[3].z,
                                  p[2].x, p[2].y, p[4].z, p[5].z, p[3].x, p[3].y, p[6].z, p[7].z};
             const nb_f2 xy4 = {p[4].x, p[4].y}, xy5 = {p[5].x, p[5].y}, xy6 = {p[6].x, p[6].y}, xy7 = {p[7].x, p[7].y};
             const nb_f2 m01 = {p[0].w, p[1].w}, m23 = {p[2].w, p[3].w}, m45 = {p[4].w, p[5].w}, m67 = {p[6].w, p[7].w};  // GENERAL
             nb_f16 ra0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
             float4 cnext = zero4;  // the next group's column bodies, loaded a group ahead
+            float enext = 0.f;     // PPS8: and their softening lengths
             {
                 const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + sl;
-                if (gc < a.n_total)
+                if (gc < a.n_total) {
                     cnext = a.pos[gc];
+                    if (PPS8)
+                        enext = a.eps_pp[gc];
+                }
             }
             for (int g = 0; g < G; ++g) {
                 const int cg = sym_group(g, wave, spacing, G);
@@ -697,17 +774,35 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
                 st[256 + lane] = st[320 + lane] = cnext.z;
                 if (GENERAL)
                     st[384 + lane] = st[448 + lane] = cnext.w;
+                if (PPS8)
+                    estage8[lane] = estage8[64 + lane] = enext * enext;
                 if (g + 1 < G) {
                     const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + sl;
                     cnext = zero4;
-                    if (gc < a.n_total)
+                    enext = 0.f;
+                    if (gc < a.n_total) {
                         cnext = a.pos[gc];
+                        if (PPS8)
+                            enext = a.eps_pp[gc];
+                    }
                 }
                 nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
                 unsigned addr = (unsigned)(size_t)lds.stage + 4u * (unsigned)lane, addr_z = addr + 1024u, cnt;
                 const unsigned next_lane = 4u * ((lane + 1) & 63);
                 const nb_f2 epsv = {a.eps2, 0.f};
-                if constexpr (GENERAL) {
+                if constexpr (PPS8) {
+                    unsigned addr_e = (unsigned)(size_t)estage8 + 4u * (unsigned)lane;
+                    asm volatile(S10_GROUP_LOOP
+                                 : "+{v[64:79]}"(ra0), "+{v[80:95]}"(ra1), "+{v[96:111]}"(ra2), "+{v[36:37]}"(cx), "+{v[40:41]}"(cy),
+                                   "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), "+{v146}"(addr_e), [cnt] "=&s"(cnt)
+                                 : "{v[12:27]}"(rows), "{v[48:49]}"(xy4), "{v[52:53]}"(xy5), "{v[56:57]}"(xy6), "{v[60:61]}"(xy7),
+                                   "{v[8:9]}"(epsv), "{v10}"(next_lane), "{v[118:119]}"(m01), "{v[122:123]}"(m23),
+                                   "{v[126:127]}"(m45), "{v[130:131]}"(m67), "{v[132:133]}"(e01), "{v[136:137]}"(e23),
+                                   "{v[140:141]}"(e45), "{v[144:145]}"(e67)
+                                 : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
+                                   "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v58", "v59", "v112", "v113",
+                                   "v114", "v115", "v116", "v117", "v134", "v135", "scc", "memory");
+                } else if constexpr (GENERAL) {
                     asm volatile(S9_GROUP_LOOP
                                  : "+{v[64:79]}"(ra0), "+{v[80:95]}"(ra1), "+{v[96:111]}"(ra2), "+{v[36:37]}"(cx), "+{v[40:41]}"(cy),
                                    "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), [cnt] "=&s"(cnt)
@@ -759,11 +854,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
     bool done = false;
     if constexpr (ROWS8 != 0 && !GUARD) {
         if (L % (kSymThreads * 8) == 0) {  // whole passes of 512 rows per wave (dummy rows would need their zero mass: see above)
-            if (uniform) {
-                passes8(std::false_type{});
+            if constexpr (ROWS8 == 3) {
+                passes8(std::integral_constant<int, 2>{});
+                done = true;
+            } else if (uniform) {
+                passes8(std::integral_constant<int, 0>{});
                 done = true;
             } else if constexpr (ROWS8 == 2) {
-                passes8(std::true_type{});
+                passes8(std::integral_constant<int, 1>{});
                 done = true;
             }
         }
@@ -837,7 +935,7 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
     const int L = a.split_len, G = L / 64;
     const SymLds lds = sym_lds<W>(smem, L);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *estage = lds.sz + L + wave * 64;
+    float *estage = lds.sz + L + wave * 128;  // 128 floats per wave are reserved (the eight-row loop stages the group twice)
     const int2 t = DIAG ? a.diag_tiles[blockIdx.x] : a.tiles[blockIdx.x];
     const int rowbase = t.x * L, colbase = t.y * L;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -957,7 +1055,7 @@ static int sym_waves(int split_len) { return split_len >= 1024 ? 4 : split_len >
 size_t symmetric_lds_bytes(int split_len)
 {
     const size_t w = (size_t)sym_waves(split_len);
-    return w * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + w * 64 * sizeof(float);
+    return w * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + w * 128 * sizeof(float);
 }
 
 template <typename K>
@@ -996,7 +1094,7 @@ static size_t sym_lds_pad()
 
 static size_t sym_lds_bytes_for(int waves, int split_len)
 {
-    return (size_t)waves * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + (size_t)waves * 64 * sizeof(float) +
+    return (size_t)waves * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + (size_t)waves * 128 * sizeof(float) +
            sym_lds_pad();
 }
 
@@ -1025,6 +1123,12 @@ hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
     // eight rows per lane for the equal-mass tiles (packed == 2): half the waves per split, 512 rows each
     // (512-body splits, one wave per workgroup, measured 0.8 % slower than the four-row loop at N = 131072: multiples of
     // 1024 only)
+    if (a.packed >= 2 && a.eps_pp && a.eps2 > 0.f && a.split_len % 1024 == 0) {  // per-particle softening: the eight-row loop S10
+        const int w8 = a.split_len % 2048 == 0 ? 4 : 2;
+        const size_t lds8 = sym_lds_bytes_for(w8, a.split_len);
+        return w8 == 4 ? sym_launch(&force_sym_kernel<4, false, 3>, a.n_tiles, 4, lds8, a, stream)
+                       : sym_launch(&force_sym_kernel<2, false, 3>, a.n_tiles, 2, lds8, a, stream);
+    }
     if ((a.packed == 2 || a.packed == 3) && !a.eps_pp && a.eps2 > 0.f && a.split_len % 1024 == 0) {
         const int w8 = a.split_len % 2048 == 0 ? 4 : 2;  // whole passes of 512 rows per wave
         const size_t lds8 = sym_lds_bytes_for(w8, a.split_len);

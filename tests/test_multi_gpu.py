@@ -182,6 +182,28 @@ def test_particle_softening_and_timing_views_on_shards():
     assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
 
 
+@pytest.mark.parametrize("world,exchange", [(2, "allgather"), (4, "ring")])
+def test_particle_softening_pair_once_shards_through_the_eight_row_loop(world, exchange):
+    """Per-particle softening in the pair-once mode with splits of 1024 bodies (the hand-scheduled S10 loop): P shards with the
+    library-owned exchange equal one context on the padded body set, bit for bit, masses arbitrary."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 30000, 2
+    pos, vel = nb.plummer(n, seed=10)
+    rng = np.random.default_rng(5)
+    pos[:, 3] *= rng.uniform(0.5, 2.0, n).astype(np.float32)
+    eps_pp = (rng.random(n) * 0.02).astype(np.float32)
+    with MultiGpuSystem(n, devices=[0] * world, force_mode="pair_once", exchange=exchange, transport="peer_copy",
+                        split_len=1024) as m:
+        m.set_state(pos, vel)
+        m.set_particle_softening(eps_pp)
+        m.step_n(steps, DT, EPS)
+        p, v = m.download()
+        n_padded = m.n_padded
+    want_p, want_v, _, _ = one_context(nb, pos, vel, n_padded, 1024, steps, force_mode="pair_once", eps_pp=eps_pp)
+    assert np.array_equal(p, want_p) and np.array_equal(v, want_v)
+
+
 def test_a_step_that_outlasts_the_timeout_is_reported_not_waited_for():
     """Failure detection: a wait longer than the timeout returns NBODY_ERR_DEVICE with a message (a dead peer looks like
     this from the survivor's side) instead of hanging."""

@@ -907,10 +907,45 @@ def test_per_particle_softening_in_the_pair_once_mode(nb, oracle_mod, eps):
     assert np.array_equal(got, sym)
 
 
-def pps_accel_mode(nb, pos, eps_pp, eps, mode, split_len):
+@pytest.mark.parametrize("n,L", [(20000, 2048), (9000, 1024), (4096, 1024)])
+def test_per_particle_softening_eight_row_loop(nb, oracle_mod, n, L):
+    """Round 3: splits of whole 1024 bodies with eps > 0 take the hand-scheduled eight-row loop with eps_j^2 staged beside
+    the columns (S10_GROUP_LOOP): against the fp64 oracle, the one-sided kernel and the compiler-scheduled pair-once kernel
+    (rows_per_lane 4 keeps it)."""
+    rng = np.random.default_rng(n + L)
+    pos, _ = nb.plummer(n, seed=47)
+    pos[:, 3] = rng.uniform(0.0, 2.0 / n, n).astype(np.float32)      # arbitrary masses, some of them tiny
+    eps_pp = rng.uniform(0.0, 0.05, n).astype(np.float32)
+    eps_pp[::7] = 0.0
+    pos[33] = pos[32]
+    pos[n - 1, :3] = pos[10, :3]
+    sym = pps_accel_mode(nb, pos, eps_pp, 1e-3, "symmetric", L)
+    one = pps_accel_mode(nb, pos, eps_pp, 1e-3, "one_sided", L)
+    want = oracle_mod.accel_f64_pps(pos, eps_pp, 1e-3)
+    assert np.isfinite(sym).all()
+    assert np.abs(sym - want).max() / np.abs(want).max() <= TOL
+    assert np.linalg.norm(sym - want) / np.linalg.norm(want) < 2e-6
+    assert np.linalg.norm(sym - one) / np.linalg.norm(one) < 1e-6
+    plain = pps_accel_mode(nb, pos, eps_pp, 1e-3, "symmetric", L, rpl=4)
+    assert np.linalg.norm(sym - plain) / np.linalg.norm(plain) < 1e-6
+    assert not np.array_equal(sym, plain)                                # two kernels: m x sum against sum of m x term
+    # summation parts and the step graph leave the bits alone
+    with nb.NBodySystem(n, split_len=L) as s:
+        s.set_force_mode("symmetric")
+        s.set_summation_parts(4)
+        s.set_particle_softening(eps_pp)
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(np.zeros_like(pos))
+        s.step(1.0, 1e-3)
+        assert np.array_equal(s.download()[1][:, :3], sym)
+
+
+def pps_accel_mode(nb, pos, eps_pp, eps, mode, split_len, rpl=0):
     n = pos.shape[0]
     with nb.NBodySystem(n, split_len=split_len) as s:
         s.set_force_mode(mode)
+        if rpl:
+            s.set_rows_per_lane(rpl)
         s.set_particle_softening(eps_pp)
         s.setParticlesPosition(pos)
         s.setParticlesVelocity(np.zeros_like(pos))
