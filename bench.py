@@ -292,7 +292,7 @@ def per_step(tm, steps):
     return out
 
 
-def peer_copy_leg(args, timeout_s=240.0):
+def peer_copy_leg(args, timeout_s=120.0):
     """The same job with the ranks' exchange done by peer copies from ONE process (nbody_multi_create over N devices,
     hipMemcpyPeerAsync instead of RCCL): a labelled secondary measurement, run in a child process after the ranks are
     done, so that a scaling curve exists even if the RCCL leg misbehaves -- and so that nothing it does can lose the main
