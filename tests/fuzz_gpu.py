@@ -2,7 +2,8 @@
 """Seeded random configurations through both force modes on one GPU: pair-once vs one-sided vs the fp64 oracle, two
 row-sharing contexts (hand-copied exchange) vs one, 1/2/4/8 summation parts, and 2-8 shards with the library-owned exchange (nbody_multi_*, peer
 copies) vs one context on the padded system.  Mass patterns: random, equal, a few species in index order (some splits
-take the equal-mass loop, some do not), massless and very heavy bodies.  python tests/fuzz_gpu.py [cases] [seed]"""
+take the equal-mass loop, some do not), massless and very heavy bodies; per-particle softening in both modes against the
+fp64 oracle.  python tests/fuzz_gpu.py [cases] [seed]"""
 import os
 import sys
 
@@ -98,6 +99,25 @@ def main():
         if eps > 0:
             assert err["one"] < 1e-5 and err["pair"] < 1e-5, (case, n, L, eps, err)
         assert err["pair"] <= max(1e-6, 3 * err["one"]), (case, n, L, eps, err)
+        if rng.random() < 0.4:                                   # per-particle softening (eps_ij^2 = eps^2 + eps_i^2 + eps_j^2)
+            eps_pp = rng.uniform(0.0, 0.05, n).astype(np.float32)
+            eps_pp[rng.random(n) < 0.2] = 0.0
+            got = {}
+            for mode in ("one_sided", "pair_once"):
+                with nb.NBodySystem(n, split_len=L) as s:
+                    s.set_force_mode(mode)
+                    s.set_particle_softening(eps_pp)
+                    s.setParticlesPosition(pos)
+                    s.setParticlesVelocity(zero4 := np.zeros_like(pos))
+                    s.step(1.0, eps)
+                    got[mode] = s.download()[1][:, :3]
+            a64 = oracle.accel_f64_pps(pos, eps_pp, eps)
+            perr = {m: np.linalg.norm(a - a64) / (np.linalg.norm(a64) + 1e-30) for m, a in got.items()}
+            assert np.isfinite(got["one_sided"]).all() and np.isfinite(got["pair_once"]).all(), (case, n, L, eps, "pps")
+            if eps > 0:
+                assert perr["one_sided"] < 1e-5 and perr["pair_once"] < 1e-5, (case, n, L, eps, perr)
+            assert perr["pair_once"] <= max(1e-6, 3 * perr["one_sided"]), (case, n, L, eps, perr)
+            worst["pps_pair_vs_f64"] = max(worst.get("pps_pair_vs_f64", 0.0), perr["pair_once"])
         for mode, whole in (("one_sided", one), ("pair_once", pair)):
             two = accel(pos, eps, mode, L, shards=2)
             if two is not None:
