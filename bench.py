@@ -389,8 +389,12 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} devices")
     torch.cuda.set_device(local_rank)
     distributed = world > 1 and not one_process
+    # NBODY_BENCH_RENDEZVOUS=gloo: the product branch below (library-owned exchange, one rank per process) with the process
+    # group on gloo -- for rehearsing it where real RCCL cannot run (several ranks on one GPU, the library linked with the
+    # RCCL test double of tests/fake_rccl: NBODY_AMD_LIBRARY).  The driver's runs never set it.
+    gloo_rendezvous = os.environ.get("NBODY_BENCH_RENDEZVOUS") == "gloo"
     if distributed:
-        if args.backend == "nccl":
+        if args.backend == "nccl" and not gloo_rendezvous:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
@@ -411,8 +415,11 @@ def main():
             kernels = system.kernels
         else:
             # nccl backend: MultiGpuSystem, the exchange inside the library; gloo: the host-staged rehearsal harness
-            system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode,
-                                    body_order=args.body_order if args.backend == "nccl" else "given")
+            if args.backend == "nccl":
+                system = MultiGpuSystem.from_torch_distributed(n, local_rank, exchange=args.exchange, force_mode=mode,
+                                                               body_order=args.body_order)
+            else:
+                system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode, body_order="given")
             kernels = system.kernels
         library_exchange = isinstance(system, MultiGpuSystem)
         rccl_ranks = system.info()["rccl_ranks"] if library_exchange else None
@@ -460,7 +467,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_rendezvous else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         local_tm = read_timing()
@@ -516,6 +523,7 @@ def main():
                        "n_bodies": n, "parallelism": f"rows sharded x{world}" if world > 1 else "1 GPU",
                        "exchange": args.exchange if world > 1 else None,
                        "backend": ("peer_copy (one process, hipMemcpyPeerAsync; secondary measurement)" if one_process else
+                                   "rccl calls of the loaded library, process group on gloo (rehearsal)" if gloo_rendezvous else
                                    "rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
                        "exchange_owner": ("library (nbody_multi_*, csrc/nbody_multi.hip)" if library_exchange else
                                           "torch.distributed rehearsal harness") if world > 1 else None,

@@ -1,0 +1,72 @@
+"""One rank of a one-rank-per-process run of the library (nbody_multi_create_rank), started by tests/test_multi_process_gpu.py
+with NBODY_AMD_LIBRARY pointing at the build that carries the RCCL test double (tests/fake_rccl): several such processes
+share cuda:0.  python tests/_multi_rank_worker.py RANK WORLD 'JSON config' WORKDIR"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import n_body_problem_amd as nb  # noqa: E402
+from n_body_problem_amd import multi  # noqa: E402
+
+
+def main():
+    rank, world, cfg, work = int(sys.argv[1]), int(sys.argv[2]), json.loads(sys.argv[3]), sys.argv[4]
+    id_file = os.path.join(work, "unique_id")
+    if rank == 0:
+        uid = multi.unique_id()
+        with open(id_file + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(id_file + ".tmp", id_file)
+    else:
+        t0 = time.time()
+        while not os.path.exists(id_file):
+            if time.time() - t0 > 120:
+                raise SystemExit("no unique id from rank 0")
+            time.sleep(0.01)
+        uid = open(id_file, "rb").read()
+    if cfg.get("die") == rank:          # a rank that never joins the steps
+        m = multi.MultiGpuSystem(cfg["n"], devices=[0], force_mode=cfg["force_mode"], _rank=rank, _world_size=world, _unique_id=uid)
+        os._exit(0)
+    n = cfg["n"]
+    pos, vel = nb.plummer(n, seed=cfg.get("seed", 77))
+    rng = np.random.default_rng(5)
+    if cfg.get("random_masses"):
+        pos[:, 3] *= rng.uniform(0.5, 2.0, n).astype(np.float32)
+    m = multi.MultiGpuSystem(n, devices=[0], force_mode=cfg["force_mode"], integrator=cfg["integrator"], exchange=cfg["exchange"],
+                             split_len=cfg.get("split_len", 0), body_order=cfg["body_order"], _rank=rank, _world_size=world,
+                             _unique_id=uid)
+    out = {"rccl_ranks": m.info()["rccl_ranks"], "world": m.world_size, "local_ranks": m.local_ranks, "rank": m.rank}
+    m.set_timeout(cfg.get("timeout", 60.0))
+    try:
+        m.set_state(pos, vel)
+        if cfg.get("pps"):
+            m.set_particle_softening((rng.random(n) * 0.02).astype(np.float32))
+        if cfg.get("reorder_every"):
+            m.set_reorder_period(cfg["reorder_every"])
+        m.timing(True)
+        m.step(cfg["dt"], cfg["eps"])
+        m.step_n(cfg["steps"] - 1, cfg["dt"], cfg["eps"])
+        if cfg.get("reorder"):
+            m.reorder()
+            m.step_n(2, cfg["dt"], cfg["eps"])
+        tm = m.read_timing(0)
+        p, v = m.download()
+        e, mom = m.energy(cfg["eps"]), m.momentum()
+        same = m.replicas_identical()
+        order = m.order() if hasattr(m, "order") and callable(m.order) else None
+    except nb.NBodyError as err:
+        with open(os.path.join(work, f"rank{rank}.json"), "w") as f:
+            json.dump({**out, "error": str(err)}, f)
+        os._exit(3)                     # no destructor may wait for a peer that is gone
+    np.savez(os.path.join(work, f"rank{rank}.npz"), p=p, v=v, e=np.asarray(e), mom=np.asarray(mom))
+    with open(os.path.join(work, f"rank{rank}.json"), "w") as f:
+        json.dump({**out, "replicas_identical": bool(same), "timing": {k: float(x) for k, x in tm.items()}}, f)
+    m.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""ONE RANK PER PROCESS -- the model the benchmark's ranks run under torchrun on a multi-GPU node (nbody_multi_create_rank,
+include/nbody.h) -- executed by 2-4 processes that share cuda:0.  Real RCCL refuses two ranks on one device, so these
+processes load a second build of the library in which the fifteen RCCL entry points are a test double that moves the bytes
+through shared memory (tests/fake_rccl; the product library always links the real librccl).  What this covers that the
+single-process peer-copy tests cannot: every place where the library must tell a LOCAL index from a GLOBAL rank, the order
+of the collective calls each rank makes, the id hand-over, the collective download / diagnostics, and what a rank reports
+when a peer is gone.  The results must equal the single-process run of the same configuration bit for bit."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DT, EPS = 1e-3, 1e-3
+
+
+@pytest.fixture(scope="module")
+def fake_library():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fake_rccl"))
+    import build_fake_rccl as fake_build
+    return fake_build.build()
+
+
+def run_ranks(fake_library, world, cfg, expect_failure=False, extra_env=None):
+    work = tempfile.mkdtemp(prefix="nbody_ranks_")
+    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, FAKE_RCCL_SLOT_MB="32", **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multi_rank_worker.py"), str(r), str(world),
+                               json.dumps(cfg), work], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung:\n" + "\n".join(logs))
+        logs.append(out)
+    if not expect_failure:
+        assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return work, [p.returncode for p in procs], logs
+
+
+def single_process(cfg, world):
+    """The same configuration with every rank in THIS process (peer copies): the established bit-exact twin of one context."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n = cfg["n"]
+    pos, vel = nb.plummer(n, seed=cfg.get("seed", 77))
+    rng = np.random.default_rng(5)
+    if cfg.get("random_masses"):
+        pos[:, 3] *= rng.uniform(0.5, 2.0, n).astype(np.float32)
+    with MultiGpuSystem(n, devices=[0] * world, force_mode=cfg["force_mode"], integrator=cfg["integrator"],
+                        exchange=cfg["exchange"], transport="peer_copy", split_len=cfg.get("split_len", 0),
+                        body_order=cfg["body_order"]) as m:
+        m.set_state(pos, vel)
+        if cfg.get("pps"):
+            m.set_particle_softening((rng.random(n) * 0.02).astype(np.float32))
+        if cfg.get("reorder_every"):
+            m.set_reorder_period(cfg["reorder_every"])
+        m.step(cfg["dt"], cfg["eps"])
+        m.step_n(cfg["steps"] - 1, cfg["dt"], cfg["eps"])
+        if cfg.get("reorder"):
+            m.reorder()
+            m.step_n(2, cfg["dt"], cfg["eps"])
+        p, v = m.download()
+        return p, v, m.energy(cfg["eps"]), m.momentum()
+
+
+CASES = [
+    (2, dict(n=5000, force_mode="one_sided", integrator="kick_drift", exchange="allgather", body_order="given", steps=3)),
+    (3, dict(n=7001, force_mode="one_sided", integrator="kdk", exchange="ring", body_order="given", steps=3)),
+    (2, dict(n=40000, force_mode="pair_once", integrator="kdk", exchange="ring", body_order="morton", steps=3, split_len=512,
+             reorder=True)),
+    (4, dict(n=30000, force_mode="pair_once", integrator="kick_drift", exchange="allgather", body_order="morton", steps=4,
+             split_len=1024, pps=True, random_masses=True, reorder_every=2)),
+    (4, dict(n=20000, force_mode="auto", integrator="kick_drift", exchange="ring", body_order="morton", steps=3)),
+]
+
+
+@pytest.mark.parametrize("world,cfg", CASES)
+def test_one_rank_per_process_equals_the_single_process_run(fake_library, world, cfg):
+    cfg = dict(cfg, dt=DT, eps=EPS)
+    work, _, logs = run_ranks(fake_library, world, cfg)
+    want_p, want_v, want_e, want_mom = single_process(cfg, world)
+    for r in range(world):
+        meta = json.load(open(os.path.join(work, f"rank{r}.json")))
+        assert meta["rccl_ranks"] == world and meta["world"] == world and meta["local_ranks"] == 1 and meta["rank"] == r
+        assert meta["replicas_identical"]
+        got = np.load(os.path.join(work, f"rank{r}.npz"))
+        assert np.array_equal(got["p"], want_p) and np.array_equal(got["v"], want_v), (r, "\n".join(logs))
+        assert np.allclose(got["e"], want_e, rtol=1e-12, atol=0) and np.allclose(got["mom"], want_mom, rtol=1e-9, atol=1e-12)
+        tm = meta["timing"]
+        assert tm["steps"] >= cfg["steps"] and tm["force_launches"] > 0 and tm["pos_exchanges"] > 0
+
+
+def test_a_rank_that_never_steps_is_reported_by_the_others(fake_library):
+    """Rank 1 creates its communicator and leaves.  The survivors must come back with an error (the library's wording, the
+    RCCL call it was in), not hang: bench.py turns that into its JSON error line."""
+    cfg = dict(n=4096, force_mode="one_sided", integrator="kick_drift", exchange="allgather", body_order="given", steps=3,
+               dt=DT, eps=EPS, die=1, timeout=10.0)
+    work, codes, logs = run_ranks(fake_library, 2, cfg, expect_failure=True, extra_env={"FAKE_RCCL_TIMEOUT_S": "5"})
+    assert codes[1] == 0 and codes[0] == 3, "\n".join(logs)
+    meta = json.load(open(os.path.join(work, "rank0.json")))
+    assert "error" in meta and "RCCL" in meta["error"]
+
+
+def test_bench_ranks_under_torchrun_with_the_rendezvous_on_gloo(fake_library):
+    """bench.py's product branch (one process per rank, library-owned exchange, per-rank breakdown, max over ranks) the way
+    the driver starts it, with two ranks on cuda:0."""
+    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, NBODY_BENCH_RENDEZVOUS="gloo", FAKE_RCCL_SLOT_MB="64")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--bodies",
+           "65536", "--single-device", "--no-extra-legs"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(x) for x in res.stdout.splitlines() if x.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["value"] > 0
+    assert line["config"]["exchange_owner"].startswith("library")
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1]
+    assert line["sanity"]["position_replicas_identical_on_all_ranks"] and abs(line["sanity"]["dE_over_E0"]) < 1e-4
