@@ -1,6 +1,7 @@
 """One rank of a one-rank-per-process run of the library (nbody_multi_create_rank), started by tests/test_multi_process_gpu.py
 with NBODY_AMD_LIBRARY pointing at the build that carries the RCCL test double (tests/fake_rccl): several such processes
-share cuda:0.  python tests/_multi_rank_worker.py RANK WORLD 'JSON config' WORKDIR"""
+share cuda:0.  python tests/_multi_rank_worker.py RANK WORLD 'JSON config' WORKDIR
+RANK = "threads": every rank as a thread of THIS process (the box allows six processes on its GPU; eight ranks need this)."""
 import json
 import os
 import sys
@@ -13,8 +14,7 @@ import n_body_problem_amd as nb  # noqa: E402
 from n_body_problem_amd import multi  # noqa: E402
 
 
-def main():
-    rank, world, cfg, work = int(sys.argv[1]), int(sys.argv[2]), json.loads(sys.argv[3]), sys.argv[4]
+def run_rank(rank, world, cfg, work):
     id_file = os.path.join(work, "unique_id")
     if rank == 0:
         uid = multi.unique_id()
@@ -66,6 +66,27 @@ def main():
     with open(os.path.join(work, f"rank{rank}.json"), "w") as f:
         json.dump({**out, "replicas_identical": bool(same), "timing": {k: float(x) for k, x in tm.items()}}, f)
     m.close()
+
+
+def main():
+    world, cfg, work = int(sys.argv[2]), json.loads(sys.argv[3]), sys.argv[4]
+    if sys.argv[1] != "threads":
+        return run_rank(int(sys.argv[1]), world, cfg, work)
+    import threading
+    failures = []
+
+    def guarded(r):
+        try:
+            run_rank(r, world, cfg, work)
+        except BaseException as e:  # noqa: BLE001 -- reported by the exit code
+            failures.append((r, repr(e)))
+    threads = [threading.Thread(target=guarded, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if failures:
+        raise SystemExit(f"ranks failed: {failures}")
 
 
 if __name__ == "__main__":

@@ -100,6 +100,24 @@ def test_one_rank_per_process_equals_the_single_process_run(fake_library, world,
         assert tm["steps"] >= cfg["steps"] and tm["force_launches"] > 0 and tm["pos_exchanges"] > 0
 
 
+def test_eight_ranks_as_eight_threads_of_one_process(fake_library):
+    """World size 8 (one row group per rank in the pair-once mode: the driver's largest run) -- as threads, because the box
+    allows six processes on its GPU.  Each thread owns one nbody_multi in the one-rank-per-process model."""
+    cfg = dict(n=50000, force_mode="pair_once", integrator="kick_drift", exchange="allgather", body_order="morton", steps=3,
+               split_len=512, reorder_every=2, dt=DT, eps=EPS)
+    work = tempfile.mkdtemp(prefix="nbody_ranks_")
+    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, FAKE_RCCL_SLOT_MB="32")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_multi_rank_worker.py"), "threads", "8", json.dumps(cfg), work],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    want_p, want_v, _, _ = single_process(cfg, 8)
+    for r in range(8):
+        meta = json.load(open(os.path.join(work, f"rank{r}.json")))
+        assert meta["rccl_ranks"] == 8 and meta["rank"] == r and meta["replicas_identical"]
+        got = np.load(os.path.join(work, f"rank{r}.npz"))
+        assert np.array_equal(got["p"], want_p) and np.array_equal(got["v"], want_v), r
+
+
 def test_a_rank_that_never_steps_is_reported_by_the_others(fake_library):
     """Rank 1 creates its communicator and leaves.  The survivors must come back with an error (the library's wording, the
     RCCL call it was in), not hang: bench.py turns that into its JSON error line."""
