@@ -389,10 +389,10 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} devices")
     torch.cuda.set_device(local_rank)
     distributed = world > 1 and not one_process
-    # NBODY_BENCH_RENDEZVOUS=gloo: the product branch below (library-owned exchange, one rank per process) with the process
+    # NBODY_RENDEZVOUS=gloo: the product branch below (library-owned exchange, one rank per process) with the process
     # group on gloo -- for rehearsing it where real RCCL cannot run (several ranks on one GPU, the library linked with the
     # RCCL test double of tests/fake_rccl: NBODY_AMD_LIBRARY).  The driver's runs never set it.
-    gloo_rendezvous = os.environ.get("NBODY_BENCH_RENDEZVOUS") == "gloo"
+    gloo_rendezvous = os.environ.get("NBODY_RENDEZVOUS") == "gloo"
     if distributed:
         if args.backend == "nccl" and not gloo_rendezvous:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

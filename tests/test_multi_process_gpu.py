@@ -132,7 +132,7 @@ def test_a_rank_that_never_steps_is_reported_by_the_others(fake_library):
 def test_bench_ranks_under_torchrun_with_the_rendezvous_on_gloo(fake_library):
     """bench.py's product branch (one process per rank, library-owned exchange, per-rank breakdown, max over ranks) the way
     the driver starts it, with two ranks on cuda:0."""
-    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, NBODY_BENCH_RENDEZVOUS="gloo", FAKE_RCCL_SLOT_MB="64")
+    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, NBODY_RENDEZVOUS="gloo", FAKE_RCCL_SLOT_MB="64")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--bodies",
            "65536", "--single-device", "--no-extra-legs"]
@@ -144,3 +144,17 @@ def test_bench_ranks_under_torchrun_with_the_rendezvous_on_gloo(fake_library):
     assert line["config"]["exchange_owner"].startswith("library")
     assert [r["rank"] for r in line["per_rank"]] == [0, 1]
     assert line["sanity"]["position_replicas_identical_on_all_ranks"] and abs(line["sanity"]["dE_over_E0"]) < 1e-4
+
+
+def test_long_run_tool_under_torchrun(fake_library):
+    """tools/run_sharded.py (BASELINE config 5's command, one process per GPU) with two ranks on cuda:0: energy reports, the
+    layout refreshed on the device, the final JSON summary."""
+    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, NBODY_RENDEZVOUS="gloo", FAKE_RCCL_SLOT_MB="32")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "tools", "run_sharded.py"), "--bodies", "32768", "--steps", "20",
+           "--energy-every", "10", "--body-order", "morton", "--reorder-every", "5", "--single-device"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(x) for x in res.stdout.splitlines() if x.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
+    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 20 and lines[0]["max_abs_dE_over_E0"] < 1e-4
+    assert sum(x.startswith("step ") for x in res.stdout.splitlines()) == 2
