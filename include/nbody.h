@@ -265,8 +265,9 @@ int nbody_sym_rowsum(nbody_ctx *ctx);
  * (kernel.cu:223, 237) and no kernel ever reads it.  With d_eps (n_total floats on the device, borrowed until replaced;
  * NULL switches it off) every pair is softened by eps_ij^2 = softening^2 + eps_i^2 + eps_j^2 in the forces and in
  * nbody_energy.  One extra add per interaction: compiler-scheduled kernel in the one-sided mode; in the pair-once mode the
- * hand-scheduled eight-row loop (softening > 0 and splits of whole 1024 bodies: 179.8 against 214.3 ms per N = 2^20 step,
- * profiles/r03_pps_modes.txt), the compiler-scheduled kernel otherwise. */
+ * hand-scheduled eight-row loop (softening > 0 and splits of whole 512 bodies, i.e. from 65 536 bodies on: 179.8 against
+ * 214.3 ms per N = 2^20 step, 0.82 against 1.01 ms at N = 65 536, profiles/r03_pps_modes.txt), the compiler-scheduled
+ * kernel otherwise. */
 int nbody_set_particle_softening(nbody_ctx *ctx, const float *d_eps);
 /* The same from n_total HOST floats, copied into a buffer the context owns (NULL switches it off). */
 int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);

@@ -392,7 +392,7 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
 // reference loads into vel.w, kernel.cu:223, and never reads).  S9 plus one packed add per (row, column pair): the column
 // pair's eps_j^2 (staged per wave, read with the positions) plus the row's eps^2 + eps_i^2 becomes the first addend of the
 // r^2 chain -- the order of force_sym_general_kernel: fma(dx, dx, (eps^2 + eps_i^2) + eps_j^2).  8.5 packed instructions + 1
-// transcendental per pair; its own kernel instantiation (ROWS8 = 3), used for splits of whole 1024 bodies and eps > 0 (a
+// transcendental per pair; its own kernel instantiation (ROWS8 = 3), used for splits of whole 512 bodies and eps > 0 (a
 // particle may have eps_i = 0: with eps = 0 the guarded compiler-scheduled kernel keeps running).
 //   EC = v[134:135] (class 1) the column pair's eps_j^2, read through v146 (its own staging array, the 64 columns twice)
 //   row terms (e0,e1) v[132:133]  (e2,e3) v[136:137]  (e4,e5) v[140:141]  (e6,e7) v[144:145]  (class 0), e_k = eps^2 + eps_k^2
@@ -1123,11 +1123,12 @@ hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
     // eight rows per lane for the equal-mass tiles (packed == 2): half the waves per split, 512 rows each
     // (512-body splits, one wave per workgroup, measured 0.8 % slower than the four-row loop at N = 131072: multiples of
     // 1024 only)
-    if (a.packed >= 2 && a.eps_pp && a.eps2 > 0.f && a.split_len % 1024 == 0) {  // per-particle softening: the eight-row loop S10
-        const int w8 = a.split_len % 2048 == 0 ? 4 : 2;
+    if (a.packed >= 2 && a.eps_pp && a.eps2 > 0.f && a.split_len % 512 == 0) {  // per-particle softening: the eight-row loop S10
+        const int w8 = a.split_len % 2048 == 0 ? 4 : a.split_len % 1024 == 0 ? 2 : 1;  // whole passes of 512 rows per wave
         const size_t lds8 = sym_lds_bytes_for(w8, a.split_len);
-        return w8 == 4 ? sym_launch(&force_sym_kernel<4, false, 3>, a.n_tiles, 4, lds8, a, stream)
-                       : sym_launch(&force_sym_kernel<2, false, 3>, a.n_tiles, 2, lds8, a, stream);
+        return w8 == 4   ? sym_launch(&force_sym_kernel<4, false, 3>, a.n_tiles, 4, lds8, a, stream)
+               : w8 == 2 ? sym_launch(&force_sym_kernel<2, false, 3>, a.n_tiles, 2, lds8, a, stream)
+                         : sym_launch(&force_sym_kernel<1, false, 3>, a.n_tiles, 1, lds8, a, stream);
     }
     if ((a.packed == 2 || a.packed == 3) && !a.eps_pp && a.eps2 > 0.f && a.split_len % 1024 == 0) {
         const int w8 = a.split_len % 2048 == 0 ? 4 : 2;  // whole passes of 512 rows per wave
