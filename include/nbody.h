@@ -264,8 +264,9 @@ int nbody_sym_rowsum(nbody_ctx *ctx);
 /* Per-particle softening: the reference loads a per-particle eps into velocities[4i+3]
  * (kernel.cu:223, 237) and no kernel ever reads it.  With d_eps (n_total floats on the device, borrowed until replaced;
  * NULL switches it off) every pair is softened by eps_ij^2 = softening^2 + eps_i^2 + eps_j^2 in the forces and in
- * nbody_energy.  One extra add per interaction: compiler-scheduled kernel in the one-sided mode; in the pair-once mode the
- * hand-scheduled eight-row loop (softening > 0 and splits of whole 512 bodies, i.e. from 65 536 bodies on: 179.8 against
+ * nbody_energy.  One extra add per interaction, inside the hand-scheduled loops: the packed one-sided loops (+8 % per step at
+ * N = 2^20, nothing at the reference's 20 225 bodies; same bits as the compiler-allocated kernel); in the pair-once mode the
+ * eight-row loop (softening > 0 and splits of whole 512 bodies, i.e. from 65 536 bodies on: 179.8 against
  * 214.3 ms per N = 2^20 step, 0.82 against 1.01 ms at N = 65 536, profiles/r03_pps_modes.txt), the compiler-scheduled
  * kernel otherwise. */
 int nbody_set_particle_softening(nbody_ctx *ctx, const float *d_eps);

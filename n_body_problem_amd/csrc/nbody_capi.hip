@@ -971,17 +971,15 @@ static int pick_rows_per_lane(const nbody_ctx *c, int split_count)
     if (c->rows_per_lane)
         return c->rows_per_lane;
     const bool short_splits = c->split_len <= 512;
-    const int64_t want[2] = {(short_splits ? 10LL : 4LL) * c->cu_count, (short_splits ? 20LL : 4LL) * c->cu_count};
+    const int64_t want[1] = {(short_splits ? 10LL : 4LL) * c->cu_count};
     const int64_t blocks4 = (c->row_count + (int64_t)kTile * 4 - 1) / ((int64_t)kTile * 4) * split_count;
     if (blocks4 >= want[0])
         return 4;
     // too few 1024-row workgroups: the same packed loop with one wave (256 rows) per workgroup -- at every size below (N =
     // 4096 ... 20 225: 29 / 34 / 59 / 78 / 121 us per step against 42 / 38 / 73 / 89 / 137 with the compiler-allocated one-row
-    // kernel, profiles/r03_small_n_blocking*.txt).  Per-particle softening runs on the compiler-allocated kernels only.
-    if (!c->eps_pp)
-        return 41;
-    const int64_t blocks2 = (c->row_count + (int64_t)kTile * 2 - 1) / ((int64_t)kTile * 2) * split_count;
-    return blocks2 >= want[1] ? 2 : 1;
+    // kernel, profiles/r03_small_n_blocking*.txt).  Per-particle softening: the same two kernels with the softening term in
+    // the loop (N = 20 225: 0.165 ms per step with the compiler-allocated one-row kernel it used to take).
+    return 41;
 }
 
 // The partial-sum array of the one-sided mode (a mode switch may need a larger one).
@@ -1326,7 +1324,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
     HIP_TRY(c, hipSetDevice(c->device));
     const int rpl = pick_rows_per_lane(c, a.split_count);
     // the one-wave kernel forms the equal-mass flag of a one-tile split from the tile it holds: no launch in front
-    a.own_split_mass = rpl == 41 && a.split_len == kTile && !a.eps_pp && c->equal_mass_path;
+    a.own_split_mass = rpl == 41 && a.split_len == kTile && c->equal_mass_path;
     if (!a.own_split_mass) {  // once per step, see the pair-once branch
         if (!c->flags_valid) {
             HIP_TRY(c, launch_split_mass(a.pos, c->split_mass, a.n_total, a.split_len, c->equal_mass_path, c->stream));

@@ -382,12 +382,58 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
+// The same loop under PER-PARTICLE SOFTENING (eps_ij^2 = eps^2 + eps_i^2 + eps_j^2): the first addend of the r^2
+// chain is formed per interaction -- (eps^2 + eps_i^2) of the two rows (ER01 = v[58:59], ER23 = v[62:63], class 1) plus the
+// column's eps_j^2, read two columns at a time from a second, scalar LDS tile (v[56:57] / v[64:65], class 0; address v66) --
+// the sum force_kernel<RPL, GUARD, true> forms, so not a bit differs.  6 (equal-mass splits) or 6.5 packed instructions + 1
+// transcendental per interaction instead of 5.5 / 6.
+#define PK_ELO " op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+#define PK_EHI " op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+#define PK_PRE_E(PXY, PZM, X, Y, Z, DX, DY, DZ, R, RLO, RHI, GRD, ER, EJ, ESEL)                                  \
+    "v_pk_add_f32 " DX ", " PXY ", " X " op_sel_hi:[0,1]" PK_NEG                                                    \
+    "v_pk_add_f32 " DY ", " PXY ", " Y " op_sel:[1,0] op_sel_hi:[1,1]" PK_NEG                                       \
+    "v_pk_add_f32 " DZ ", " PZM ", " Z " op_sel_hi:[0,1]" PK_NEG                                                    \
+    "v_pk_add_f32 " R ", " ER ", " EJ ESEL                                                                          \
+    "v_pk_fma_f32 " R ", " DX ", " DX ", " R "\n\t"                                                                  \
+    "v_pk_fma_f32 " R ", " DY ", " DY ", " R "\n\t"                                                                  \
+    "v_pk_fma_f32 " R ", " DZ ", " DZ ", " R "\n\t" GRD(RLO) GRD(RHI)
+#define PK_COLUMN_E(PXY, PZM, NEXT, GRD, POST, EJ, ESEL)                                                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    PK_PRE_E(PXY, PZM, "v[14:15]", "v[18:19]", "v[12:13]", "v[30:31]", "v[34:35]", "v[38:39]", "v[20:21]", "v20", "v21", GRD, \
+             "v[58:59]", EJ, ESEL)                                                                               \
+    PK_PRE_E(PXY, PZM, "v[22:23]", "v[26:27]", "v[16:17]", "v[42:43]", "v[46:47]", "v[50:51]", "v[24:25]", "v24", "v25", GRD, \
+             "v[62:63]", EJ, ESEL)                                                                               \
+    "v_rsq_f32_e32 v20, v20\n\tv_rsq_f32_e32 v21, v21\n\tv_rsq_f32_e32 v24, v24\n\tv_rsq_f32_e32 v25, v25\n\t"       \
+    NEXT NB_R4_GAP NB_R4_PRIO_POST                                                                               \
+    POST(PZM, "v[28:29]", "v[32:33]", "v[36:37]", "v[30:31]", "v[34:35]", "v[38:39]", "v[20:21]")             \
+    POST(PZM, "v[40:41]", "v[44:45]", "v[48:49]", "v[42:43]", "v[46:47]", "v[50:51]", "v[24:25]")             \
+    NB_R4_PRIO_PRE
+#define PK_TILE_LOOP_E(GRD, POST)                                                                                \
+    NB_R4_PRIO_PRE                                                                                               \
+    "ds_read_b128 v[0:3], v52\n\t"                                                                               \
+    "ds_read2_b32 v[56:57], v66 offset1:1\n\t"                                                                   \
+    "s_mov_b32 %[cnt], 64\n"                                                                                     \
+    "1:\n\t"                                                                                                     \
+    PK_COLUMN_E("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:16\n\tds_read2_b32 v[64:65], v66 offset0:2 offset1:3\n\t", \
+                GRD, POST, "v[56:57]", PK_ELO)                                                                   \
+    PK_COLUMN_E("v[4:5]", "v[6:7]", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD, POST, "v[56:57]", PK_EHI)       \
+    PK_COLUMN_E("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:48\n\tds_read2_b32 v[56:57], v66 offset0:4 offset1:5\n\t", \
+                GRD, POST, "v[64:65]", PK_ELO)                                                                   \
+    PK_COLUMN_E("v[4:5]", "v[6:7]", "v_add_u32_e32 v52, 64, v52\n\tv_add_u32_e32 v66, 16, v66\n\tds_read_b128 v[0:3], v52\n\t", \
+                GRD, POST, "v[64:65]", PK_EHI)                                                                   \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"
+
 typedef float nb_f2 __attribute__((ext_vector_type(2)));
 
-template <bool GUARD>
+template <bool GUARD, bool PPS = false>
 __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
 {
     __shared__ float4 tile[2 * kTile + 1];
+    __shared__ float etile[PPS ? 2 * kTile + 2 : 1];  // eps_j^2 of the tile's columns (+ 2: the loop's last read-ahead)
 
     const int tid = threadIdx.x;
     int split = a.split_first + blockIdx.y;
@@ -404,36 +450,78 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
     const bool uniform = split_mass == split_mass;
 
     float4 p[4];
+    float er[4];  // PPS: eps^2 + eps_i^2 of the rows
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = row_base + k * kTile;
         p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < a.row_count)
+        float e = 0.f;
+        if (r < a.row_count) {
             p[k] = a.pos[a.row_lo + r];
+            if (PPS)
+                e = a.eps_pp[a.row_lo + r];
+        }
+        er[k] = __builtin_fmaf(e, e, a.eps2);
     }
     const nb_f2 x01 = {p[0].x, p[1].x}, y01 = {p[0].y, p[1].y}, z01 = {p[0].z, p[1].z};
     const nb_f2 x23 = {p[2].x, p[3].x}, y23 = {p[2].y, p[3].y}, z23 = {p[2].z, p[3].z};
+    const nb_f2 er01 = {er[0], er[1]}, er23 = {er[2], er[3]};
     nb_f2 ax01 = {0.f, 0.f}, ay01 = ax01, az01 = ax01, ax23 = ax01, ay23 = ax01, az23 = ax01;
     const nb_f2 epsv = {a.eps2, 0.f};
     const float tiny = kGuardMin, pinf = __builtin_inff();
 
     float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j0 + tid < j1)
+    float stage_e = 0.f;
+    if (j0 + tid < j1) {
         stage = a.pos[j0 + tid];
+        if (PPS)
+            stage_e = a.eps_pp[j0 + tid];
+    }
     tile[tid] = stage;
+    if (PPS)
+        etile[tid] = stage_e * stage_e;
     if (tid == 0)
         tile[2 * kTile] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PPS && tid < 2)
+        etile[2 * kTile + tid] = 0.f;
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int jn = j0 + (t + 1) * kTile + tid;
         if (t + 1 < ntiles) {
             stage = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (jn < j1)
+            stage_e = 0.f;
+            if (jn < j1) {
                 stage = a.pos[jn];
+                if (PPS)
+                    stage_e = a.eps_pp[jn];
+            }
         }
         unsigned lds = (unsigned)(size_t)(&tile[(t & 1) * kTile]);
         unsigned cnt;
+        if constexpr (PPS) {
+            unsigned elds = (unsigned)(size_t)(&etile[(t & 1) * kTile]);
+#define PK_OPERANDS_E                                                                                                 \
+            : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),      \
+              "+{v[48:49]}"(az23), "+{v52}"(lds), "+{v66}"(elds), [cnt] "=&s"(cnt)                                        \
+            : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23),              \
+              "{v[16:17]}"(z23), "{v[58:59]}"(er01), "{v[62:63]}"(er23), "{v10}"(tiny), "{v11}"(pinf)                    \
+            : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35",     \
+              "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v56", "v57", "v64", "v65", "scc",    \
+              "vcc", "memory"
+            if (GUARD)
+                asm volatile(PK_TILE_LOOP_E(PK_GUARD, PK_POST) PK_OPERANDS_E);
+            else if (uniform)
+                asm volatile(PK_TILE_LOOP_E(PK_NOGUARD, PK_POSTU) PK_OPERANDS_E);
+            else
+                asm volatile(PK_TILE_LOOP_E(PK_NOGUARD, PK_POST) PK_OPERANDS_E);
+            if (t + 1 < ntiles) {
+                tile[((t + 1) & 1) * kTile + tid] = stage;
+                etile[((t + 1) & 1) * kTile + tid] = stage_e * stage_e;
+            }
+            __syncthreads();
+            continue;
+        }
 #define PK_OPERANDS                                                                                                   \
         : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),          \
           "+{v[48:49]}"(az23), "+{v52}"(lds), [cnt] "=&s"(cnt)                                                            \
@@ -472,10 +560,11 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
 // the wave holds the split's 256 masses in registers and forms the same flag itself (one launch less per step).
 // ONE_TILE: every split is one 256-column tile (split_len = 256): no second LDS buffer, no columns in flight under the
 // loop -- 16 VGPRs and 4 KiB of LDS less, so that the six or seven waves a SIMD gets at N = 20 225 are all resident at once.
-template <bool GUARD, bool ONE_TILE>
+template <bool GUARD, bool ONE_TILE, bool PPS = false>
 __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
 {
     __shared__ float4 tile[(ONE_TILE ? 1 : 2) * kTile + 1];
+    __shared__ float etile[PPS ? (ONE_TILE ? 1 : 2) * kTile + 2 : 1];  // per-particle softening: eps_j^2 of the columns
 
     const int lane = threadIdx.x;
     int split = a.split_first + blockIdx.y;
@@ -487,26 +576,38 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
     const int row_base = blockIdx.x * kTile + 4 * (lane & 15) + (lane >> 4);  // rows row_base + 64 k: see force_kernel_r4pk
 
     float4 p[4];
+    float er[4];  // PPS: eps^2 + eps_i^2 of the rows
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = row_base + k * 64;
         p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < a.row_count)
+        float e = 0.f;
+        if (r < a.row_count) {
             p[k] = a.pos[a.row_lo + r];
+            if (PPS)
+                e = a.eps_pp[a.row_lo + r];
+        }
+        er[k] = __builtin_fmaf(e, e, a.eps2);
     }
     const nb_f2 x01 = {p[0].x, p[1].x}, y01 = {p[0].y, p[1].y}, z01 = {p[0].z, p[1].z};
     const nb_f2 x23 = {p[2].x, p[3].x}, y23 = {p[2].y, p[3].y}, z23 = {p[2].z, p[3].z};
+    const nb_f2 er01 = {er[0], er[1]}, er23 = {er[2], er[3]};
     nb_f2 ax01 = {0.f, 0.f}, ay01 = ax01, az01 = ax01, ax23 = ax01, ay23 = ax01, az23 = ax01;
     const nb_f2 epsv = {a.eps2, 0.f};
     const float tiny = kGuardMin, pinf = __builtin_inff();
 
     float4 stage[4];  // four columns of the tile per lane; an out-of-range column is a zero-mass body at the origin
+    float stage_e[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = j0 + k * 64 + lane;
         stage[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < j1)
+        stage_e[k] = 0.f;
+        if (c < j1) {
             stage[k] = a.pos[c];
+            if (PPS)
+                stage_e[k] = a.eps_pp[c];
+        }
     }
     // the one mass of the split's bodies, as split_mass_kernel defines it (nbody_symmetric.hip): from the tile in registers
     // when the split is this one tile, else from the flags the launch in front has written
@@ -528,10 +629,15 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
     const bool uniform = split_mass == split_mass;
 
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) {
         tile[k * 64 + lane] = stage[k];
+        if (PPS)
+            etile[k * 64 + lane] = stage_e[k] * stage_e[k];
+    }
     if (lane == 0)
         tile[(ONE_TILE ? 1 : 2) * kTile] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PPS && lane < 2)
+        etile[(ONE_TILE ? 1 : 2) * kTile + lane] = 0.f;
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -540,12 +646,35 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
             for (int k = 0; k < 4; ++k) {
                 const int c = j0 + (t + 1) * kTile + k * 64 + lane;
                 stage[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < j1)
+                stage_e[k] = 0.f;
+                if (c < j1) {
                     stage[k] = a.pos[c];
+                    if (PPS)
+                        stage_e[k] = a.eps_pp[c];
+                }
             }
         }
         unsigned lds = (unsigned)(size_t)(&tile[ONE_TILE ? 0 : (t & 1) * kTile]);
         unsigned cnt;
+        if constexpr (PPS) {
+            unsigned elds = (unsigned)(size_t)(&etile[ONE_TILE ? 0 : (t & 1) * kTile]);
+            if (GUARD)
+                asm volatile(PK_TILE_LOOP_E(PK_GUARD, PK_POST) PK_OPERANDS_E);
+            else if (uniform)
+                asm volatile(PK_TILE_LOOP_E(PK_NOGUARD, PK_POSTU) PK_OPERANDS_E);
+            else
+                asm volatile(PK_TILE_LOOP_E(PK_NOGUARD, PK_POST) PK_OPERANDS_E);
+            if (!ONE_TILE && t + 1 < ntiles) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tile[((t + 1) & 1) * kTile + k * 64 + lane] = stage[k];
+                    etile[((t + 1) & 1) * kTile + k * 64 + lane] = stage_e[k] * stage_e[k];
+                }
+            }
+            if (!ONE_TILE)
+                __syncthreads();
+            continue;
+        }
 #define PK_OPERANDS                                                                                                   \
         : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),          \
           "+{v[48:49]}"(az23), "+{v52}"(lds), [cnt] "=&s"(cnt)                                                            \
@@ -580,6 +709,19 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
 static hipError_t launch_forces_r4pk_w1(const ForceArgs &a, hipStream_t stream)
 {
     dim3 grid((a.row_count + kTile - 1) / kTile, a.split_count, 1);
+    if (a.eps_pp) {  // per-particle softening (a particle may have eps = 0: the guard stays on when eps = 0)
+        if (a.split_len == kTile) {
+            if (a.eps2 > 0.f)
+                hipLaunchKernelGGL((force_kernel_r4pk_w1<false, true, true>), grid, dim3(64), 0, stream, a);
+            else
+                hipLaunchKernelGGL((force_kernel_r4pk_w1<true, true, true>), grid, dim3(64), 0, stream, a);
+        } else if (a.eps2 > 0.f) {
+            hipLaunchKernelGGL((force_kernel_r4pk_w1<false, false, true>), grid, dim3(64), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((force_kernel_r4pk_w1<true, false, true>), grid, dim3(64), 0, stream, a);
+        }
+        return hipGetLastError();
+    }
     if (a.split_len == kTile) {
         if (a.eps2 > 0.f)
             hipLaunchKernelGGL((force_kernel_r4pk_w1<false, true>), grid, dim3(64), 0, stream, a);
@@ -596,10 +738,16 @@ static hipError_t launch_forces_r4pk_w1(const ForceArgs &a, hipStream_t stream)
 static hipError_t launch_forces_r4pk(const ForceArgs &a, hipStream_t stream)
 {
     dim3 grid((a.row_count + kTile * 4 - 1) / (kTile * 4), a.split_count, 1);
-    if (a.eps2 > 0.f)
-        hipLaunchKernelGGL(force_kernel_r4pk<false>, grid, dim3(kTile), 0, stream, a);
-    else
-        hipLaunchKernelGGL(force_kernel_r4pk<true>, grid, dim3(kTile), 0, stream, a);
+    if (a.eps_pp) {
+        if (a.eps2 > 0.f)
+            hipLaunchKernelGGL((force_kernel_r4pk<false, true>), grid, dim3(kTile), 0, stream, a);
+        else
+            hipLaunchKernelGGL((force_kernel_r4pk<true, true>), grid, dim3(kTile), 0, stream, a);
+    } else if (a.eps2 > 0.f) {
+        hipLaunchKernelGGL((force_kernel_r4pk<false, false>), grid, dim3(kTile), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((force_kernel_r4pk<true, false>), grid, dim3(kTile), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -641,9 +789,9 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
     switch (rows_per_lane) {
     case 1: return launch_forces_rpl<1>(a, stream);
     case 2: return launch_forces_rpl<2>(a, stream);
-    case 4: return a.eps_pp ? launch_forces_rpl<4>(a, stream) : launch_forces_r4pk(a, stream);     // packed fp32 (default)
+    case 4: return launch_forces_r4pk(a, stream);     // packed fp32 (default); per-particle softening: its own loop
     case 40: return a.eps_pp ? launch_forces_rpl<4>(a, stream) : launch_forces_r4_asm(a, stream);  // one row per instruction
-    case 41: return a.eps_pp ? launch_forces_rpl<1>(a, stream) : launch_forces_r4pk_w1(a, stream);  // packed, one wave per workgroup
+    case 41: return launch_forces_r4pk_w1(a, stream);  // packed, one wave per workgroup
     case -4: return launch_forces_rpl<4>(a, stream);
     case 8: return launch_forces_rpl<8>(a, stream);
     default: return hipErrorInvalidValue;

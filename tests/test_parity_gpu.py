@@ -839,6 +839,38 @@ def test_per_particle_softening_matches_oracle(nb, oracle_mod, n, eps):
     assert np.abs(uni - glob).max() / np.abs(glob).max() <= TOL
 
 
+@pytest.mark.parametrize("n,split_len,eps,masses", [(5000, 256, 1e-3, "equal"), (5000, 256, 0.0, "random"), (7000, 1024, 1e-3, "random"),
+                                                    (3001, 512, 0.0, "equal"), (20225, 0, 1e-2, "species")])
+def test_per_particle_softening_hand_scheduled_one_sided_loops(nb, oracle_mod, n, split_len, eps, masses):
+    """Round 3: the packed one-sided loops (1024-row workgroups, rows_per_lane 4; one wave per workgroup, 41 -- what small
+    systems take by default) carry the softening term themselves.  Same FMA chain per row as the compiler-allocated kernel
+    (rows_per_lane -4): equal bits, for one-tile and longer splits, with and without the zero-distance guard, equal and
+    arbitrary masses."""
+    pos, _ = nb.plummer(n, seed=n)
+    rng = np.random.default_rng(n)
+    if masses == "random":
+        pos[:, 3] = rng.uniform(0.0, 2.0 / n, n).astype(np.float32)
+    elif masses == "species":
+        pos[n // 3:, 3] *= np.float32(3.0)
+    eps_pp = rng.uniform(0.0, 0.05, n).astype(np.float32)
+    eps_pp[::5] = 0.0
+    pos[21] = pos[20]
+    got = {}
+    for rpl in (-4, 4, 41, 0):
+        with nb.NBodySystem(n, split_len=split_len) as s:
+            s.set_rows_per_lane(rpl)
+            s.set_particle_softening(eps_pp)
+            s.setParticlesPosition(pos)
+            s.setParticlesVelocity(np.zeros_like(pos))
+            s.step(1.0, eps)
+            got[rpl] = s.download()[1][:, :3]
+    assert np.isfinite(got[-4]).all()
+    for rpl in (4, 41, 0):
+        assert np.array_equal(got[rpl], got[-4]), rpl
+    want = oracle_mod.accel_f64_pps(pos, eps_pp, eps)
+    assert np.abs(got[0] - want).max() / np.abs(want).max() <= TOL
+
+
 def test_per_particle_softening_shards_and_energy(nb, oracle_mod):
     n, split_len = 6000, 512
     pos, vel = nb.plummer(n, seed=42)
