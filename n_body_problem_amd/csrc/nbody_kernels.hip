@@ -427,6 +427,16 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
+// operands of PK_TILE_LOOP_E in both packed kernels
+#define PK_OPERANDS_E                                                                                                 \
+        : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),      \
+          "+{v[48:49]}"(az23), "+{v52}"(lds), "+{v66}"(elds), [cnt] "=&s"(cnt)                                        \
+        : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23),              \
+          "{v[16:17]}"(z23), "{v[58:59]}"(er01), "{v[62:63]}"(er23), "{v10}"(tiny), "{v11}"(pinf)                    \
+        : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35",     \
+          "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v56", "v57", "v64", "v65", "scc",    \
+          "vcc", "memory"
+
 typedef float nb_f2 __attribute__((ext_vector_type(2)));
 
 template <bool GUARD, bool PPS = false>
@@ -501,14 +511,6 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
         unsigned cnt;
         if constexpr (PPS) {
             unsigned elds = (unsigned)(size_t)(&etile[(t & 1) * kTile]);
-#define PK_OPERANDS_E                                                                                                 \
-            : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),      \
-              "+{v[48:49]}"(az23), "+{v52}"(lds), "+{v66}"(elds), [cnt] "=&s"(cnt)                                        \
-            : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23),              \
-              "{v[16:17]}"(z23), "{v[58:59]}"(er01), "{v[62:63]}"(er23), "{v10}"(tiny), "{v11}"(pinf)                    \
-            : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35",     \
-              "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v56", "v57", "v64", "v65", "scc",    \
-              "vcc", "memory"
             if (GUARD)
                 asm volatile(PK_TILE_LOOP_E(PK_GUARD, PK_POST) PK_OPERANDS_E);
             else if (uniform)

@@ -9,8 +9,9 @@
 // one rank creates and distributes; collectives and grouped send/recv pairs that every rank must call in the same order;
 // results in the receive buffers once the stream has passed the call.  What it drops: asynchrony (every call, or the
 // ncclGroupEnd that closes a group, waits for the stream, moves the bytes through a POSIX shared-memory segment with two
-// barriers, and returns when the data is in place) and speed.  A rank that never arrives makes the others fail with
-// ncclSystemError after FAKE_RCCL_TIMEOUT_S (default 120) seconds instead of hanging.
+// barriers, and returns when the data is in place) and speed.  A rank that never arrives -- or one that fails locally before a
+// barrier and returns early -- makes the others fail with ncclSystemError after FAKE_RCCL_TIMEOUT_S (default 120) seconds
+// instead of hanging.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
