@@ -355,7 +355,9 @@ extern "C" int nbody_multi_create(nbody_multi **out, const nbody_multi_config *c
     int rc = create_common(out, cfg, n_devices, &m);
     if (rc != NBODY_OK)
         return rc;
-    if (rccl(m))
+    // NBODY_RCCL_ALLOW_SHARED_DEVICE: tests that link the RCCL test double (tests/fake_rccl) run this path with every rank on
+    // one device; real RCCL reports duplicate devices itself
+    if (rccl(m) && !getenv("NBODY_RCCL_ALLOW_SHARED_DEVICE"))
         for (int i = 0; i < n_devices; ++i)
             for (int j = 0; j < i; ++j)
                 if (devices[i] == devices[j]) {

@@ -68,8 +68,41 @@ def run_rank(rank, world, cfg, work):
     m.close()
 
 
+def run_all_local(world, cfg, work):
+    """Every rank in THIS process behind one nbody_multi (nbody_multi_create, NBODY_TRANSPORT_RCCL: ncclCommInitAll, every
+    collective of all ranks inside one ncclGroupStart/End) -- what host/nbody_run --devices and MultiGpuSystem(devices=[...])
+    run on a multi-GPU node."""
+    n = cfg["n"]
+    pos, vel = nb.plummer(n, seed=cfg.get("seed", 77))
+    rng = np.random.default_rng(5)
+    if cfg.get("random_masses"):
+        pos[:, 3] *= rng.uniform(0.5, 2.0, n).astype(np.float32)
+    with multi.MultiGpuSystem(n, devices=[0] * world, force_mode=cfg["force_mode"], integrator=cfg["integrator"],
+                              exchange=cfg["exchange"], transport="rccl", split_len=cfg.get("split_len", 0),
+                              body_order=cfg["body_order"]) as m:
+        info = m.info()
+        m.set_state(pos, vel)
+        if cfg.get("pps"):
+            m.set_particle_softening((rng.random(n) * 0.02).astype(np.float32))
+        if cfg.get("reorder_every"):
+            m.set_reorder_period(cfg["reorder_every"])
+        m.step(cfg["dt"], cfg["eps"])
+        m.step_n(cfg["steps"] - 1, cfg["dt"], cfg["eps"])
+        if cfg.get("reorder"):
+            m.reorder()
+            m.step_n(2, cfg["dt"], cfg["eps"])
+        p, v = m.download()
+        e, mom, same = m.energy(cfg["eps"]), m.momentum(), m.replicas_identical()
+    np.savez(os.path.join(work, "rank0.npz"), p=p, v=v, e=np.asarray(e), mom=np.asarray(mom))
+    with open(os.path.join(work, "rank0.json"), "w") as f:
+        json.dump({"rccl_ranks": info["rccl_ranks"], "world": info["world_size"], "local_ranks": info["local_ranks"],
+                   "replicas_identical": bool(same)}, f)
+
+
 def main():
     world, cfg, work = int(sys.argv[2]), json.loads(sys.argv[3]), sys.argv[4]
+    if sys.argv[1] == "all_local":
+        return run_all_local(world, cfg, work)
     if sys.argv[1] != "threads":
         return run_rank(int(sys.argv[1]), world, cfg, work)
     import threading

@@ -5,7 +5,9 @@
 //
 // It is linked INTO a second build of the library (tests/fake_rccl/libnbody_amd_fake_rccl.so = the product's object files +
 // this file, -Bsymbolic, no -lrccl: tests/fake_rccl/build_fake_rccl.py); the product library itself always links the real librccl.
-// Only tests load it (NBODY_AMD_LIBRARY).  What it keeps of RCCL's contract: a communicator of `world` ranks made from an id
+// Only tests load it (NBODY_AMD_LIBRARY).  Both ways the library makes communicators are covered: ncclCommInitRank (one rank per
+// process, the segment) and ncclCommInitAll (all ranks in one process, one thread, every collective inside one group: plain
+// memory instead of the segment, no barriers).  What it keeps of RCCL's contract: a communicator of `world` ranks made from an id
 // one rank creates and distributes; collectives and grouped send/recv pairs that every rank must call in the same order;
 // results in the receive buffers once the stream has passed the call.  What it drops: asynchrony (every call, or the
 // ncclGroupEnd that closes a group, waits for the stream, moves the bytes through a POSIX shared-memory segment with two
@@ -21,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -81,6 +84,7 @@ struct ncclComm {
     Shared *sh = nullptr;
     size_t map_bytes = 0;
     bool failed = false;
+    bool local = false;  // ncclCommInitAll: all ranks in this process, the "segment" is plain memory shared by its communicators
     std::string last_error;
     char *slot(int r) const { return reinterpret_cast<char *>(sh) + sh->header_bytes + (size_t)r * sh->slot_bytes; }
 };
@@ -151,26 +155,18 @@ const Message *find_message(const ncclComm *c, int r, uint32_t kind, int dst, in
     return nullptr;
 }
 
-ncclResult_t run(std::vector<Op> &ops)
+// what rank c sends in this group, into its slot
+ncclResult_t write_phase(ncclComm *c, const std::vector<Op> &ops)
 {
-    if (ops.empty())
-        return ncclSuccess;
-    ncclComm *c = ops[0].comm;
-    for (const Op &o : ops)
-        if (o.comm != c)  // several communicators in one group = several ranks in one process: not what this double is for
-            return fail(c, ncclInvalidUsage, "one rank per process only (use NBODY_TRANSPORT_PEER_COPY for local ranks)");
-    if (c->failed)
-        return ncclSystemError;
     for (const Op &o : ops)  // everything the stream was given before the call has happened
-        if (hipStreamSynchronize(o.stream) != hipSuccess)
+        if (o.comm == c && hipStreamSynchronize(o.stream) != hipSuccess)
             return fail(c, ncclUnhandledCudaError, "hipStreamSynchronize");
-    // what this rank sends, into its slot
     char *p = c->slot(c->rank);
     const char *end = p + c->sh->slot_bytes;
     uint64_t n_msgs = 0;
     char *q = p + kAlign;
     for (const Op &o : ops) {
-        if (o.kind == kRecv)
+        if (o.comm != c || o.kind == kRecv)
             continue;
         if (q + kAlign + aligned(o.bytes) > end)
             return fail(c, ncclInternalError, "the messages of one group exceed FAKE_RCCL_SLOT_MB");
@@ -182,13 +178,18 @@ ncclResult_t run(std::vector<Op> &ops)
         ++n_msgs;
     }
     std::memcpy(p, &n_msgs, sizeof n_msgs);
-    if (!barrier(c))
-        return ncclSystemError;
-    // what this rank receives
+    return ncclSuccess;
+}
+
+// what rank c receives in this group, out of the slots of all ranks
+ncclResult_t read_phase(ncclComm *c, const std::vector<Op> &ops)
+{
     ncclResult_t rc = ncclSuccess;
     int n_gather = 0, n_reduce = 0;
     std::vector<int> n_recv((size_t)c->world, 0);
     for (const Op &o : ops) {
+        if (o.comm != c)
+            continue;
         if (o.kind == kAllGather) {
             for (int r = 0; r < c->world && rc == ncclSuccess; ++r) {
                 const Message *m = find_message(c, r, kAllGather, 0, n_gather);
@@ -236,6 +237,51 @@ ncclResult_t run(std::vector<Op> &ops)
         if (rc != ncclSuccess)
             break;
     }
+    return rc;
+}
+
+ncclResult_t run(std::vector<Op> &ops)
+{
+    if (ops.empty())
+        return ncclSuccess;
+    ncclComm *c = ops[0].comm;
+    if (c->local) {
+        // every rank of the communicator lives in this process (ncclCommInitAll) and one thread drives them all: a group must
+        // hold the calls of ALL ranks (as a real collective would need), their messages are written first, then delivered
+        std::vector<ncclComm *> comms;
+        for (const Op &o : ops) {
+            if (!o.comm->local || o.comm->sh != c->sh)
+                return fail(c, ncclInvalidUsage, "a group mixes communicators of different worlds");
+            bool seen = false;
+            for (ncclComm *k : comms)
+                seen |= k == o.comm;
+            if (!seen)
+                comms.push_back(o.comm);
+        }
+        if ((int)comms.size() != c->world)
+            return fail(c, ncclInvalidUsage, "a group holds the calls of " + std::to_string(comms.size()) + " of " +
+                                                 std::to_string(c->world) + " ranks: a real collective would wait for ever");
+        for (ncclComm *k : comms)
+            if (k->failed)
+                return ncclSystemError;
+        ncclResult_t rc = ncclSuccess;
+        for (size_t i = 0; i < comms.size() && rc == ncclSuccess; ++i)
+            rc = write_phase(comms[i], ops);
+        for (size_t i = 0; i < comms.size() && rc == ncclSuccess; ++i)
+            rc = read_phase(comms[i], ops);
+        return rc;
+    }
+    for (const Op &o : ops)
+        if (o.comm != c)  // several communicators of the one-rank-per-process kind in one group
+            return fail(c, ncclInvalidUsage, "one communicator per group in the one-rank-per-process model");
+    if (c->failed)
+        return ncclSystemError;
+    ncclResult_t rc = write_phase(c, ops);
+    if (rc != ncclSuccess)
+        return rc;
+    if (!barrier(c))
+        return ncclSystemError;
+    rc = read_phase(c, ops);
     if (!barrier(c))  // nobody rewrites a slot before everybody has read it (entered even after a local error)
         return ncclSystemError;
     return rc;
@@ -346,12 +392,43 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int r
     return ncclSuccess;
 }
 
-ncclResult_t ncclCommInitAll(ncclComm_t *, int, const int *) { return ncclInvalidUsage; }  // one rank per process only
+// Every rank in this process (the library's nbody_multi_create with NBODY_TRANSPORT_RCCL): the communicators share a block of
+// plain memory laid out like the segment; the block is freed with the last of them.
+ncclResult_t ncclCommInitAll(ncclComm_t *comms, int n, const int *)
+{
+    if (!comms || n < 1)
+        return ncclInvalidArgument;
+    const char *mb = getenv("FAKE_RCCL_SLOT_MB");
+    const uint64_t slot_bytes = (uint64_t)(mb ? atol(mb) : 64) << 20;
+    const uint64_t header = aligned(sizeof(Shared)) + 4096;
+    const size_t bytes = header + (size_t)n * slot_bytes;
+    void *mem = std::calloc(1, bytes);
+    if (!mem)
+        return ncclSystemError;
+    Shared *sh = new (mem) Shared;
+    sh->world = (uint32_t)n;
+    sh->slot_bytes = slot_bytes;
+    sh->header_bytes = header;
+    sh->arrived.store((uint32_t)n);  // here: the number of communicators still alive
+    for (int i = 0; i < n; ++i) {
+        ncclComm *c = new ncclComm;
+        c->rank = i;
+        c->world = n;
+        c->sh = sh;
+        c->map_bytes = bytes;
+        c->local = true;
+        comms[i] = c;
+    }
+    return ncclSuccess;
+}
 
 ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
     if (c) {
-        munmap(c->sh, c->map_bytes);
+        if (!c->local)
+            munmap(c->sh, c->map_bytes);
+        else if (c->sh->arrived.fetch_sub(1) == 1)
+            std::free(c->sh);
         delete c;
     }
     return ncclSuccess;

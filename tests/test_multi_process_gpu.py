@@ -100,6 +100,30 @@ def test_one_rank_per_process_equals_the_single_process_run(fake_library, world,
         assert tm["steps"] >= cfg["steps"] and tm["force_launches"] > 0 and tm["pos_exchanges"] > 0
 
 
+@pytest.mark.parametrize("world,cfg", [
+    (2, dict(n=6000, force_mode="one_sided", integrator="kdk", exchange="ring", body_order="given", steps=3)),
+    (4, dict(n=30000, force_mode="pair_once", integrator="kick_drift", exchange="allgather", body_order="morton", steps=4,
+             split_len=512, pps=True, random_masses=True, reorder_every=2)),
+    (8, dict(n=50000, force_mode="pair_once", integrator="kdk", exchange="ring", body_order="morton", steps=3, split_len=256,
+             reorder=True))])
+def test_all_ranks_in_one_process_over_the_rccl_calls(fake_library, world, cfg):
+    """The other way the library uses RCCL: ONE process, one communicator per device from ncclCommInitAll, the calls of all
+    ranks inside one group (nbody_multi_create with NBODY_TRANSPORT_RCCL: host/nbody_run --devices ..., MultiGpuSystem(devices=
+    [...])).  All ranks on cuda:0 over the test double; equal to the peer-copy transport bit for bit."""
+    cfg = dict(cfg, dt=DT, eps=EPS)
+    work = tempfile.mkdtemp(prefix="nbody_ranks_")
+    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, FAKE_RCCL_SLOT_MB="32", NBODY_RCCL_ALLOW_SHARED_DEVICE="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_multi_rank_worker.py"), "all_local", str(world),
+                          json.dumps(cfg), work], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    meta = json.load(open(os.path.join(work, "rank0.json")))
+    assert meta["rccl_ranks"] == world and meta["local_ranks"] == world and meta["replicas_identical"]
+    want_p, want_v, want_e, want_mom = single_process(cfg, world)
+    got = np.load(os.path.join(work, "rank0.npz"))
+    assert np.array_equal(got["p"], want_p) and np.array_equal(got["v"], want_v)
+    assert np.allclose(got["e"], want_e, rtol=1e-12, atol=0) and np.allclose(got["mom"], want_mom, rtol=1e-9, atol=1e-12)
+
+
 def test_eight_ranks_as_eight_threads_of_one_process(fake_library):
     """World size 8 (one row group per rank in the pair-once mode: the driver's largest run) -- as threads, because the box
     allows six processes on its GPU.  Each thread owns one nbody_multi in the one-rank-per-process model."""
