@@ -8,23 +8,63 @@
 //   nbody_run --file galaxy.bin --steps 1000 --dump-every 100 --dump-prefix out/gal
 //   nbody_run --resume out/gal_000500.nbs --steps 500
 //   nbody_run --plummer 1048576 --devices 0,1,2,3,4,5,6,7 --pair-once --steps 10     rows sharded over 8 GPUs, RCCL inside
+//   mpirun -np 8 nbody_run --plummer 4194304 --ranks-from-env --id-file /tmp/nbody.id --auto --steps 1000 --energy-every 100
+//                                                        one process per GPU (rank / world size / local rank from the launcher's
+//                                                        environment, or --rank R --world P [--device D]); rank 0 reports
 //
 // Build: g++ -O2 -std=c++17 -Iinclude host/nbody_run.cpp -Ln_body_problem_amd -lnbody_amd -Wl,-rpath,'$ORIGIN/../n_body_problem_amd'
 #include "../include/nbody.hpp"
 #include "nbody_io.hpp"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 static void usage()
 {
     std::cerr << "usage: nbody_run [dataset_id 0-5] [--data-dir DIR] [--file PATH] [--plummer N] [--seed S] [--resume SNAPSHOT]\n"
                  "                 [--steps K] [--dt DT] [--softening EPS] [--energy-every M] [--dump-every M] [--dump-prefix P] [--morton [--reorder-every M]]\n"
                  "                 [--pad-reference] [--device D] [--final SNAPSHOT] [--kdk] [--pair-once | --auto] [--particle-softening]\n"
-                 "                 [--devices D0,D1,...] [--ring] [--peer-copy]      rows sharded over several GPUs (library-owned exchange)\n";
+                 "                 [--devices D0,D1,...] [--ring] [--peer-copy]      rows sharded over several GPUs (library-owned exchange)\n"
+                 "                 [--rank R --world P | --ranks-from-env] --id-file PATH   the same with one process per GPU: rank 0 writes the\n"
+                 "                                  communicator id to PATH (a path every rank sees), the others wait for it; --device D or LOCAL_RANK\n";
+}
+
+// The first of these variables that is set, as an integer (launchers: torchrun, Open MPI, MPICH / Slurm).
+static int env_int(std::initializer_list<const char *> names, int fallback)
+{
+    for (const char *n : names)
+        if (const char *v = std::getenv(n))
+            return std::atoi(v);
+    return fallback;
+}
+
+// Rank 0 creates the communicator id and publishes it through a file (written beside it, then renamed: never seen half
+// written); the other ranks wait for the file.
+static std::vector<unsigned char> exchange_id(int rank, const std::string &path)
+{
+    if (path.empty()) throw std::runtime_error("one process per GPU needs --id-file PATH (a path all ranks see)");
+    if (rank == 0) {
+        if (std::ifstream(path).good())  // a leftover of another run would be read by the ranks that start before this one
+            throw std::runtime_error(path + " exists already: remove it or give this run its own --id-file");
+        const std::vector<unsigned char> id = nbody::MultiSystem::uniqueId();
+        const std::string tmp = path + ".tmp";
+        { std::ofstream f(tmp, std::ios::binary | std::ios::trunc); f.write(reinterpret_cast<const char *>(id.data()), (std::streamsize)id.size()); }
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot write " + path);
+        return id;
+    }
+    for (int waited_ms = 0; waited_ms < 120000; waited_ms += 10) {
+        std::ifstream f(path, std::ios::binary);
+        std::vector<unsigned char> id((size_t)NBODY_UNIQUE_ID_BYTES);
+        if (f && f.read(reinterpret_cast<char *>(id.data()), (std::streamsize)id.size())) return id;
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    throw std::runtime_error("no communicator id in " + path + " after 120 s (is rank 0 running?)");
 }
 
 int main(int argc, char **argv)
@@ -37,6 +77,9 @@ int main(int argc, char **argv)
     bool pad = false, kdk = false, pair_once = false, particle_eps = false, ring = false, peer_copy = false, morton = false;
     bool auto_mode = false;  // --auto: the library picks the force mode by body count (nbody_create_auto / NBODY_FORCE_AUTO)
     std::vector<int> devices;
+    int rank = 0, world = 1;   // one process per GPU: --rank / --world or the launcher's environment
+    bool device_given = false;
+    std::string id_file;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
@@ -57,7 +100,15 @@ int main(int argc, char **argv)
         else if (a == "--pair-once") pair_once = true;
         else if (a == "--auto") auto_mode = true;
         else if (a == "--particle-softening") particle_eps = true;
-        else if (a == "--device") device = std::atoi(next().c_str());
+        else if (a == "--device") { device = std::atoi(next().c_str()); device_given = true; }
+        else if (a == "--rank") rank = std::atoi(next().c_str());
+        else if (a == "--world") world = std::atoi(next().c_str());
+        else if (a == "--id-file") id_file = next();
+        else if (a == "--ranks-from-env") {
+            rank = env_int({"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"}, 0);
+            world = env_int({"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, 1);
+            if (!device_given) device = env_int({"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"}, 0);
+        }
         else if (a == "--devices") {
             std::stringstream list(next());
             for (std::string tok; std::getline(list, tok, ',');) devices.push_back(std::atoi(tok.c_str()));
@@ -72,6 +123,10 @@ int main(int argc, char **argv)
             if (dataset < 0 || dataset > 5) { std::cerr << "dataset id must be 0..5\n"; return 2; }
         } else { usage(); return 2; }
     }
+    if (world < 1 || rank < 0 || rank >= world) { std::cerr << "--rank must lie in [0, --world)\n"; return 2; }
+    if (world > 1 && !devices.empty()) { std::cerr << "--devices (one process, several GPUs) and --world (one process per GPU) exclude each other\n"; return 2; }
+    const bool per_process = world > 1;
+    const bool report = rank == 0;          // one process per GPU: every rank computes, rank 0 prints and writes files
     try {
         nbody_io::Bodies b;
         std::int64_t step0 = 0;
@@ -82,11 +137,12 @@ int main(int argc, char **argv)
         else b = nbody_io::plummer(plummer_n > 0 ? plummer_n : 65536, seed);
         const std::int64_t n_real = b.n();
         if (pad) nbody_io::pad_reference_style(b);  // accepted, never required (kernel.cu:260-278)
-        std::printf("num of Bodies = %lld (real %lld)  dt = %g  softening = %g\n", (long long)b.n(), (long long)n_real, dt, softening);
+        if (report)
+            std::printf("num of Bodies = %lld (real %lld)  dt = %g  softening = %g\n", (long long)b.n(), (long long)n_real, dt, softening);
         // --morton: the bodies are stored along a Morton curve (nbody_morton_order: neighbours in memory are neighbours in
         // space, the force kernels' operands toggle fewer bits, the power-limited clock rises); snapshots keep the file's order
         std::vector<std::int64_t> order;
-        if (morton && b.n() > 0 && devices.empty()) {  // (with --devices the library does it: nbody_multi_config.body_order)
+        if (morton && b.n() > 0 && devices.empty() && !per_process) {  // (sharded: the library does it, nbody_multi_config.body_order)
             order.resize((size_t)b.n());
             if (nbody_morton_order(b.pos.data(), b.n(), order.data()) != NBODY_OK) throw std::runtime_error("nbody_morton_order failed");
             nbody_io::Bodies sorted = b;
@@ -108,9 +164,12 @@ int main(int argc, char **argv)
             nbody_io::save_snapshot(name, out, step, time);
         };
 
-        if (!devices.empty()) {  // rows sharded over the listed GPUs; everything per step happens inside the library
+        if (!devices.empty() || per_process) {  // rows sharded over GPUs; everything per step happens inside the library
             nbody::MultiSystem ms;
-            ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy, 0, morton, auto_mode);
+            if (per_process)   // this process is one rank of `world`; every call below is collective
+                ms.initializeRank(b.n(), device, rank, world, exchange_id(rank, id_file), pair_once, kdk, ring, 0, morton, auto_mode);
+            else
+                ms.initialize(b.n(), devices, pair_once, kdk, ring, peer_copy, 0, morton, auto_mode);
             ms.setState(b.pos.data(), b.vel.data());
             if (morton && reorder_every > 0) ms.setReorderPeriod(reorder_every);
             ms.timing(true);
@@ -120,12 +179,14 @@ int main(int argc, char **argv)
                 ms.setParticleSoftening(eps.data());
             }
             auto inf = ms.info();
-            std::printf("ranks = %lld (RCCL communicator of %lld)  padded bodies = %lld  rows per rank = %lld  split = %lld\n",
+            if (report)
+                std::printf("ranks = %lld (RCCL communicator of %lld)  padded bodies = %lld  rows per rank = %lld  split = %lld\n",
                         (long long)inf[4], (long long)inf[6], (long long)inf[1], (long long)inf[2], (long long)inf[3]);
             nbody::System::Energy e0{};
             if (energy_every > 0) {
                 e0 = ms.energy(softening);
-                std::printf("step %lld  E = %.9e (K %.6e U %.6e)\n", (long long)step0, e0.total, e0.kinetic, e0.potential);
+                if (report)
+                    std::printf("step %lld  E = %.9e (K %.6e U %.6e)\n", (long long)step0, e0.total, e0.kinetic, e0.potential);
             }
             const auto t0 = std::chrono::steady_clock::now();
             std::int64_t s = 0;
@@ -139,32 +200,39 @@ int main(int argc, char **argv)
                 if (energy_every > 0 && (s % energy_every == 0 || s == steps)) {
                     auto e = ms.energy(softening);
                     auto p = ms.momentum();
-                    std::printf("step %lld  E = %.9e  dE/E0 = %+.3e  |p| = %.3e\n", (long long)gs, e.total,
+                    if (report)
+                        std::printf("step %lld  E = %.9e  dE/E0 = %+.3e  |p| = %.3e\n", (long long)gs, e.total,
                                 (e.total - e0.total) / std::fabs(e0.total), std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
                 }
                 if (dump_every > 0 && s % dump_every == 0) {
-                    ms.download(b.pos.data(), b.vel.data());
+                    ms.download(b.pos.data(), b.vel.data());  // collective; every rank receives all rows
                     char name[512];
                     std::snprintf(name, sizeof name, "%s_%06lld.nbs", dump_prefix.c_str(), (long long)gs);
-                    save(name, gs, time0 + (double)s * dt);
+                    if (report)
+                        save(name, gs, time0 + (double)s * dt);
                 }
             }
             const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const double inter = (double)b.n() * (double)b.n() * (double)steps;
-            std::printf("%lld steps in %.3f s: %.3f ms/step, %.3e interactions/s; replicas identical: %s\n", (long long)steps, wall,
-                        1e3 * wall / (double)steps, inter / wall, ms.replicasIdentical() ? "yes" : "NO");
+            const bool identical = ms.replicasIdentical();  // collective
+            if (report)
+                std::printf("%lld steps in %.3f s: %.3f ms/step, %.3e interactions/s; replicas identical: %s\n", (long long)steps, wall,
+                            1e3 * wall / (double)steps, inter / wall, identical ? "yes" : "NO");
             for (int i = 0; i < (int)inf[5]; ++i) {  // where every local rank's step went (library event totals, ms per step)
                 const auto t = ms.readRankTiming(i);
                 const double k = (double)std::max<std::int64_t>(1, t.steps);
                 std::printf("  rank %d: force kernels %.3f  behind them %.3f  position exchange %.3f on the wire, %.3f as the waiting "
-                            "launch saw it  column sums %.3f  host enqueue %.3f  layout refreshes %lld (%.3f ms each)\n", i,
+                            "launch saw it  column sums %.3f  host enqueue %.3f  layout refreshes %lld (%.3f ms each)\n", rank + i,
                             t.forceMs / k, t.updateMs / k, t.posExchangeCommMs / k, t.posExchangeWaitMs / k, t.columnSumExchangeMs / k,
                             t.hostEnqueueMs / k, (long long)t.reorders, t.reorders ? t.reorderMs / (double)t.reorders : 0.0);
             }
             if (!final_path.empty()) {
                 ms.download(b.pos.data(), b.vel.data());
-                save(final_path, step0 + steps, time0 + (double)steps * dt);
+                if (report)
+                    save(final_path, step0 + steps, time0 + (double)steps * dt);
             }
+            if (per_process && report)
+                std::remove(id_file.c_str());  // every rank has joined the communicator long ago
             return 0;
         }
         nbody::System sys;

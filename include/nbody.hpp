@@ -157,6 +157,34 @@ public:
         check(nbody_multi_create(&m_, &cfg, devices.data(), (int)devices.size()), "nbody_multi_create");
         n_ = numBodies;
     }
+    // One rank per process (mpirun / torchrun --no-python / a job script): rank 0 calls uniqueId() and hands the bytes to the
+    // other ranks by any channel; every rank then calls initializeRank with them.  From setState on all calls are collective.
+    static std::vector<unsigned char> uniqueId()
+    {
+        std::vector<unsigned char> id(NBODY_UNIQUE_ID_BYTES);
+        if (nbody_multi_unique_id(id.data()) != NBODY_OK)
+            throw std::runtime_error(std::string("nbody_multi_unique_id: ") + nbody_multi_last_error(nullptr));
+        return id;
+    }
+    void initializeRank(std::int64_t numBodies, int device, int rank, int worldSize, const std::vector<unsigned char> &id,
+                        bool pairOnce = false, bool kickDriftKick = false, bool ring = false, std::int64_t splitLen = 0,
+                        bool mortonOrder = false, bool autoMode = false)
+    {
+        if (id.size() != NBODY_UNIQUE_ID_BYTES)
+            throw std::runtime_error("MultiSystem::initializeRank: the unique id has NBODY_UNIQUE_ID_BYTES bytes");
+        nbody_multi_destroy(m_);
+        m_ = nullptr;
+        nbody_multi_config cfg{};
+        cfg.n_bodies = numBodies;
+        cfg.split_len = splitLen;
+        cfg.force_mode = autoMode ? NBODY_FORCE_AUTO : pairOnce ? NBODY_FORCE_SYMMETRIC : NBODY_FORCE_ONE_SIDED;
+        cfg.integrator = kickDriftKick ? NBODY_INTEGRATOR_KDK : NBODY_INTEGRATOR_KICK_DRIFT;
+        cfg.exchange = ring ? NBODY_EXCHANGE_RING : NBODY_EXCHANGE_ALLGATHER;
+        cfg.transport = NBODY_TRANSPORT_RCCL;
+        cfg.body_order = mortonOrder ? NBODY_ORDER_MORTON : NBODY_ORDER_GIVEN;
+        check(nbody_multi_create_rank(&m_, &cfg, device, rank, worldSize, id.data()), "nbody_multi_create_rank");
+        n_ = numBodies;
+    }
     void setState(const float *xyzm, const float *xyzw) { check(nbody_multi_set_state(m_, xyzm, xyzw), "nbody_multi_set_state"); }
     // the reference's two setters, independent copies (kernel.cu:163-188)
     void setParticlesPosition(const float *xyzm) { check(nbody_multi_set_positions(m_, xyzm), "nbody_multi_set_positions"); }

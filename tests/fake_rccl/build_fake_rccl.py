@@ -36,5 +36,25 @@ def build(force: bool = False) -> str:
     return LIB
 
 
+HOST = os.path.join(HERE, "nbody_run_fake_rccl")
+
+
+def build_host(force: bool = False) -> str:
+    """host/nbody_run.cpp linked against the library above: the C++ host's one-process-per-GPU mode on one GPU."""
+    lib = build(force)
+    src = os.path.join(ROOT, "host", "nbody_run.cpp")
+    deps = [src, os.path.join(ROOT, "host", "nbody_io.hpp"), os.path.join(ROOT, "include", "nbody.hpp"),
+            os.path.join(ROOT, "include", "nbody.h"), lib]
+    if not force and os.path.exists(HOST) and all(os.path.getmtime(d) <= os.path.getmtime(HOST) for d in deps):
+        return HOST
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-L" + HERE, "-lnbody_amd_fake_rccl",
+           "-L/opt/rocm/lib", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-o", HOST]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed building the host against the RCCL test double:\n" + res.stderr[-4000:])
+    return HOST
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_host(force=True))

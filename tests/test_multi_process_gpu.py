@@ -182,3 +182,37 @@ def test_long_run_tool_under_torchrun(fake_library):
     assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
     assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 20 and lines[0]["max_abs_dE_over_E0"] < 1e-4
     assert sum(x.startswith("step ") for x in res.stdout.splitlines()) == 2
+
+
+@pytest.mark.parametrize("world,flags", [(2, ["--pair-once", "--kdk"]), (4, ["--auto", "--morton", "--reorder-every", "2", "--ring"])])
+def test_cpp_host_one_process_per_gpu(fake_library, tmp_path, world, flags):
+    """host/nbody_run with --rank / --world / --id-file (one process per GPU: the thin C++ host under mpirun or a job script),
+    the ranks sharing cuda:0 over the test double: energy reports and snapshots from rank 0, and the final state equal to the
+    single-process run (--devices 0,0,... --peer-copy) byte for byte."""
+    from n_body_problem_amd import build as product
+    import build_fake_rccl as fake_build
+    exe = fake_build.build_host()
+    common = ["--plummer", "40000", "--steps", "6", "--dt", "1e-3", "--softening", "1e-3", "--energy-every", "3", *flags]
+    id_file = tmp_path / "comm.id"
+    env = dict(os.environ, FAKE_RCCL_SLOT_MB="32")
+    procs = [subprocess.Popen([exe, *common, "--rank", str(r), "--world", str(world), "--device", "0", "--id-file", str(id_file),
+                               "--final", str(tmp_path / "ranks.nbs")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(world)]
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung:\n" + "\n".join(outs))
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
+    assert "dE/E0" in outs[0] and "replicas identical: yes" in outs[0] and f"RCCL communicator of {world}" in outs[0]
+    assert all("dE/E0" not in o for o in outs[1:])                  # rank 0 reports
+    assert not id_file.exists()                                     # and removes the id file
+    one = subprocess.run([product.build_host(), *common, "--devices", ",".join(["0"] * world), "--peer-copy", "--final",
+                          str(tmp_path / "one.nbs")], capture_output=True, text=True, timeout=240)
+    assert one.returncode == 0, one.stderr
+    assert (tmp_path / "ranks.nbs").read_bytes() == (tmp_path / "one.nbs").read_bytes()
+    energies = lambda text: [ln.split("E =")[1].split()[0] for ln in text.splitlines() if ln.startswith("step ")]  # noqa: E731
+    assert energies(outs[0]) == energies(one.stdout)
