@@ -266,9 +266,9 @@ int nbody_sym_rowsum(nbody_ctx *ctx);
  * NULL switches it off) every pair is softened by eps_ij^2 = softening^2 + eps_i^2 + eps_j^2 in the forces and in
  * nbody_energy.  One extra add per interaction, inside the hand-scheduled loops: the packed one-sided loops (+8 % per step at
  * N = 2^20, nothing at the reference's 20 225 bodies; same bits as the compiler-allocated kernel); in the pair-once mode the
- * eight-row loop (softening > 0 and splits of whole 512 bodies, i.e. from 65 536 bodies on: 179.8 against
- * 214.3 ms per N = 2^20 step, 0.82 against 1.01 ms at N = 65 536, profiles/r03_pps_modes.txt), the compiler-scheduled
- * kernel otherwise. */
+ * eight-row loop (softening > 0, splits of whole 512 bodies, i.e. from 65 536 bodies on: 179.8 against 214.3 ms per
+ * N = 2^20 step, 0.82 against 1.01 ms at N = 65 536, profiles/r03_pps_modes.txt) or the four-row loop (other split
+ * lengths: 0.48 against 0.58 ms at N = 49 152); with softening = 0 the compiler-scheduled, guarded kernel. */
 int nbody_set_particle_softening(nbody_ctx *ctx, const float *d_eps);
 /* The same from n_total HOST floats, copied into a buffer the context owns (NULL switches it off). */
 int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);

@@ -504,6 +504,63 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
+// ---- the four-row loop for arbitrary masses under PER-PARTICLE SOFTENING (splits that are not whole multiples of 512 bodies:
+// systems below 65 536 bodies): S3 plus one packed add per (row, column pair) -- (eps_j^2 of the two columns, read with the
+// positions from a per-wave staging array through v86) + (eps^2 + eps_i^2 of the row, from the pairs (e0, e1) = v[84:85] and
+// (e2, e3) = v[88:89], class 0) becomes the first addend of the r^2 chain, EC = v[82:83] (class 1).  9 packed instructions +
+// 1 transcendental per pair; its own kernel instantiation (ROWS8 = 4), eps > 0 only.
+#define S11_PRE(RXY, RZM, DX, DY, DZ, R, ER, ESEL)                                                               \
+    "v_pk_add_f32 " DX ", v[2:3], " RXY " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                      \
+    "v_pk_add_f32 " DY ", v[6:7], " RXY " op_sel:[0,1] op_sel_hi:[1,1]" S2_NEG                                      \
+    "v_pk_add_f32 " DZ ", v[4:5], " RZM " op_sel:[0,0] op_sel_hi:[1,0]" S2_NEG                                      \
+    "v_pk_add_f32 " R ", v[82:83], " ER ESEL "\n\t"                                                                \
+    "v_pk_fma_f32 " R ", " DX ", " DX ", " R "\n\t"                                                                  \
+    "v_pk_fma_f32 " R ", " DY ", " DY ", " R "\n\t"                                                                  \
+    "v_pk_fma_f32 " R ", " DZ ", " DZ ", " R "\n\t"
+#define S11_LO " op_sel:[0,0] op_sel_hi:[1,0]"
+#define S11_HI " op_sel:[0,1] op_sel_hi:[1,1]"
+#define S11_EPS(E0, E1) "ds_read2_b32 v[82:83], v86 offset0:" E0 " offset1:" E1 "\n\t"
+#define S11_ADVANCE S2_ADVANCE "v_add_u32_e32 v86, 16, v86\n\t"
+#define S11_STEP(NEXT, NEXT_MASSES)                                                                              \
+    "s_waitcnt lgkmcnt(7)\n\t" /* positions and eps_j^2 of the column pair have arrived (masses, permutes may be in flight) */ \
+    S11_PRE("v[12:13]", "v[14:15]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]", "v[84:85]", S11_LO)          \
+    S11_PRE("v[16:17]", "v[18:19]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]", "v[84:85]", S11_HI)          \
+    "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
+    NB_SYM_GAP                                                                                                   \
+    "s_waitcnt lgkmcnt(0)\n\t" /* the masses and the column sums have arrived */                                 \
+    NB_SYM_PRIO_POST                                                                                             \
+    S3_POST("v[14:15]", "v[56:57]", "v[58:59]", "v[60:61]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")      \
+    S3_POST("v[18:19]", "v[62:63]", "v[64:65]", "v[66:67]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S11_PRE("v[20:21]", "v[22:23]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]", "v[88:89]", S11_LO)          \
+    S11_PRE("v[24:25]", "v[26:27]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]", "v[88:89]", S11_HI)          \
+    NEXT /* the next step's positions and eps_j^2 */                                                             \
+    "v_rsq_f32_e32 v28, v28\n\tv_rsq_f32_e32 v29, v29\n\tv_rsq_f32_e32 v32, v32\n\tv_rsq_f32_e32 v33, v33\n\t"       \
+    NB_SYM_GAP                                                                                                   \
+    NB_SYM_PRIO_POST                                                                                             \
+    S3_POST("v[22:23]", "v[68:69]", "v[70:71]", "v[72:73]", "v[30:31]", "v[34:35]", "v[38:39]", "v[28:29]")      \
+    S3_POST("v[26:27]", "v[74:75]", "v[76:77]", "v[78:79]", "v[42:43]", "v[46:47]", "v[50:51]", "v[32:33]")      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    NEXT_MASSES /* the next step's masses */                                                                     \
+    S2_ROTATE
+#define S11_GROUP_LOOP                                                                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    S2_READ("0", "32", "128", "160") S11_EPS("0", "32")                                                          \
+    S3_MASSES("128", "160")                                                                                      \
+    S2_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 8\n"                                                                                      \
+    "1:\n\t"                                                                                                     \
+    S11_STEP(S2_READ("1", "33", "129", "161") S11_EPS("1", "33"), S3_MASSES("129", "161"))                       \
+    S11_STEP(S2_READ("2", "34", "130", "162") S11_EPS("2", "34"), S3_MASSES("130", "162"))                       \
+    S11_STEP(S2_READ("3", "35", "131", "163") S11_EPS("3", "35"), S3_MASSES("131", "163"))                       \
+    S11_STEP(S11_ADVANCE S2_READ("0", "32", "128", "160") S11_EPS("0", "32"), S3_MASSES("128", "160"))           \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"
+
 // ring distance of the tile (R, C): its slot in the partial-sum arrays
 __device__ __forceinline__ int sym_distance(int R, int C, int S)
 {
@@ -547,12 +604,13 @@ __device__ __forceinline__ int sym_group(int g, int wave, int spacing, int G)
 typedef float nb_f16 __attribute__((ext_vector_type(16)));
 // ROWS8 = 1: equal-mass tiles through the eight-rows-per-lane loop (<= 128 VGPRs: four waves per SIMD), the others through
 // the four-row loops; 2: the eight-row loops for both kinds of tile (S9_GROUP_LOOP needs ~150 VGPRs: three waves per SIMD);
-// 3: every tile through S10_GROUP_LOOP (per-particle softening, ~160 VGPRs: three waves per SIMD)
+// 3: every tile through S10_GROUP_LOOP (per-particle softening, ~160 VGPRs: three waves per SIMD); 4: every tile through the
+// four-row S11_GROUP_LOOP (per-particle softening where a split is not a whole multiple of 512 bodies; four waves per SIMD)
 #ifndef NB_S8_WAVES
 #define NB_S8_WAVES 4  /* waves per SIMD the eight-row equal-mass kernel is allocated for */
 #endif
 template <int W, bool GUARD, int ROWS8 = 0>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 >= 2 ? 3 : ROWS8 == 1 ? NB_S8_WAVES : 5))) void force_sym_kernel(SymArgs a)  // ROWS8 = 0: <= 96 VGPRs
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 == 4 ? 4 : ROWS8 >= 2 ? 3 : ROWS8 == 1 ? NB_S8_WAVES : 5))) void force_sym_kernel(SymArgs a)  // ROWS8 = 0: <= 96 VGPRs
 {
     constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -568,7 +626,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 >=
     const float mass_rows = GUARD ? __builtin_nanf("") : a.split_mass[t.x], mass_cols = GUARD ? mass_rows : a.split_mass[t.y];
     // ... and only when every pass is full: the lanes of a partial last pass (split lengths that are not a multiple of the
     // rows per pass, e.g. 768 with two waves) carry dummy rows whose zero MASS is what keeps them out of the column sums
-    const bool uniform = ROWS8 != 3 && !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;  // 3: masses in the loop
+    const bool uniform = ROWS8 < 3 && !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;  // 3: masses in the loop
     const float row_scale = uniform ? mass_cols : 1.f, col_scale = uniform ? mass_rows : 1.f;
 
     for (int c = tid; c < L; c += kSymThreads)
@@ -576,29 +634,42 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 >=
     __syncthreads();
 
     auto passes = [&](auto variant_tag) {  // one copy of the loops per inner-loop variant: no merged live ranges
-    // 0 general masses, 1 equal-mass tile (one column per step); packed, two columns per step: 2 equal-mass tile, 3 general masses
+    // 0 general masses, 1 equal-mass tile (one column per step); packed, two columns per step: 2 equal-mass tile, 3 general masses,
+    // 4 general masses + per-particle softening
     constexpr int VARIANT = decltype(variant_tag)::value;
     constexpr bool PACKED = VARIANT >= 2;
+    constexpr bool PPS4 = VARIANT == 4;
+    float *estage4 = lds.sz + L + wave * 128;  // PPS4: the group's eps_j^2, the 64 columns twice
     constexpr bool UNIFORM = VARIANT == 1;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);  // a local of the lambda: a captured one would live in scratch
     for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
         nb_f4 row[kSymRows];
         float ax[kSymRows], ay[kSymRows], az[kSymRows];
+        float er[kSymRows];  // PPS4: eps^2 + eps_i^2 of the rows
 #pragma unroll
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
             float4 p = zero4;
-            if (r < L && rowbase + r < row_hi)
+            float e = 0.f;
+            if (r < L && rowbase + r < row_hi) {
                 p = a.pos[rowbase + r];
+                if (PPS4)
+                    e = a.eps_pp[rowbase + r];
+            }
             row[k] = nb_f4{p.x, p.y, p.z, p.w};
+            er[k] = __builtin_fmaf(e, e, a.eps2);
             ax[k] = ay[k] = az[k] = 0.f;
         }
 
         float4 cnext = zero4;  // the next group's column bodies, loaded a group ahead
+        float enext = 0.f;     // PPS4: and their softening lengths
         {
             const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + lane;
-            if (gc < a.n_total)
+            if (gc < a.n_total) {
                 cnext = a.pos[gc];
+                if (PPS4)
+                    enext = a.eps_pp[gc];
+            }
         }
         nb_f2 ra[kSymRows][3];  // VARIANT 2: row sums per column of the pair
 #pragma unroll
@@ -611,16 +682,50 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 >=
                 st[lane] = st[64 + lane] = cnext.x;
                 st[128 + lane] = st[192 + lane] = cnext.y;
                 st[256 + lane] = st[320 + lane] = cnext.z;
-                if (VARIANT == 3)
+                if (VARIANT >= 3)
                     st[384 + lane] = st[448 + lane] = cnext.w;
+                if (PPS4)
+                    estage4[lane] = estage4[64 + lane] = enext * enext;
             } else {
                 lds.stage[lane] = cnext;
             }
             if (g + 1 < G) {
                 const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + lane;
                 cnext = zero4;
-                if (gc < a.n_total)
+                enext = 0.f;
+                if (gc < a.n_total) {
                     cnext = a.pos[gc];
+                    if (PPS4)
+                        enext = a.eps_pp[gc];
+                }
+            }
+            if constexpr (VARIANT == 4) {
+                nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
+                unsigned addr = (unsigned)(size_t)lds.stage + 4u * (unsigned)lane, addr_zm = addr + 1024u, cnt;
+                unsigned addr_e = (unsigned)(size_t)estage4 + 4u * (unsigned)lane;
+                const unsigned next_lane = 4u * ((lane + 1) & 63);
+                const nb_f2 e01 = {er[0], er[1]}, e23 = {er[2], er[3]};
+                asm volatile(S11_GROUP_LOOP
+                             : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
+                               "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
+                               "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_zm), "+{v0}"(addr),
+                               "+{v86}"(addr_e), [cnt] "=&s"(cnt)
+                             : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
+                               "{v[84:85]}"(e01), "{v[88:89]}"(e23), "{v53}"(next_lane)
+                             : "v2", "v3", "v4", "v5", "v6", "v7", "v10", "v11", "v28", "v29", "v30", "v31", "v32", "v33", "v34",
+                               "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v80", "v81", "v82",
+                               "v83", "scc", "memory");
+                const int ca = cg * 64 + ((lane + 32) & 63), cb = cg * 64 + lane;  // as in the equal-mass loop below
+                lds.sx[ca] -= cx.x;
+                lds.sy[ca] -= cy.x;
+                lds.sz[ca] -= cz.x;
+                lds.sx[cb] -= cx.y;
+                lds.sy[cb] -= cy.y;
+                lds.sz[cb] -= cz.y;
+                if ((g + 1) % spacing == 0)
+                    __syncthreads();
+                continue;
             }
             if constexpr (VARIANT == 3) {
                 nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
@@ -866,16 +971,20 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 >=
             }
         }
     }
-    if (done)
-        ;
-    else if (uniform && a.packed)
-        passes(std::integral_constant<int, 2>{});
-    else if (uniform)
-        passes(std::integral_constant<int, 1>{});
-    else if (!GUARD && a.packed)
-        passes(std::integral_constant<int, 3>{});
-    else
-        passes(std::integral_constant<int, 0>{});
+    if constexpr (ROWS8 == 4 && !GUARD) {  // per-particle softening, four rows per lane: the only loop of this instantiation
+        passes(std::integral_constant<int, 4>{});
+    } else {
+        if (done)
+            ;
+        else if (uniform && a.packed)
+            passes(std::integral_constant<int, 2>{});
+        else if (uniform)
+            passes(std::integral_constant<int, 1>{});
+        else if (!GUARD && a.packed)
+            passes(std::integral_constant<int, 3>{});
+        else
+            passes(std::integral_constant<int, 0>{});
+    }
 
     float3 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);  // P_col[R][d-1][.]
     for (int c = tid; c < L; c += kSymThreads)
@@ -1101,7 +1210,11 @@ static size_t sym_lds_bytes_for(int waves, int split_len)
 template <int W>
 static hipError_t sym_launch_tiles(const SymArgs &a, size_t lds, hipStream_t stream)
 {
-    if (a.eps_pp)  // per-particle softening: the compiler-scheduled kernel (a particle may have eps = 0: keep the guard at eps = 0)
+    // per-particle softening: the four-row loop S11 with eps > 0; with eps = 0 a particle may have eps_i = 0 too and the guarded,
+    // compiler-scheduled kernel runs (NBODY_SYM_PACKED=0 / rows_per_lane 4: that kernel always -- A/B, tests)
+    if (a.eps_pp && a.eps2 > 0.f && a.packed >= 2)
+        return sym_launch(&force_sym_kernel<W, false, 4>, a.n_tiles, W, lds, a, stream);
+    if (a.eps_pp)
         return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<W, false, false, true>, a.n_tiles, W, lds, a, stream)
                             : sym_launch(&force_sym_general_kernel<W, false, true, true>, a.n_tiles, W, lds, a, stream);
     return a.eps2 > 0.f ? sym_launch(&force_sym_kernel<W, false>, a.n_tiles, W, lds, a, stream)

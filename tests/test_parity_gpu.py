@@ -939,9 +939,12 @@ def test_per_particle_softening_in_the_pair_once_mode(nb, oracle_mod, eps):
     assert np.array_equal(got, sym)
 
 
-@pytest.mark.parametrize("n,L", [(20000, 2048), (9000, 1024), (4096, 1024), (9000, 512), (1536, 512)])
+@pytest.mark.parametrize("n,L", [(20000, 2048), (9000, 1024), (4096, 1024), (9000, 512), (1536, 512), (9000, 256), (5000, 768),
+                                 (700, 256), (6000, 1280)])
 def test_per_particle_softening_eight_row_loop(nb, oracle_mod, n, L):
-    """Round 3: splits of whole 512 bodies with eps > 0 take the hand-scheduled eight-row loop with eps_j^2 staged beside
+    """Round 3: with eps > 0 the pair-once tiles take hand-scheduled loops that carry the softening term -- splits of whole 512
+    bodies the eight-row loop (S10), the others the four-row loop (S11) -- instead of the compiler-scheduled kernel
+    (rows_per_lane 4 keeps it).  Splits of whole 512 bodies: the eight-row loop with eps_j^2 staged beside
     the columns (S10_GROUP_LOOP): against the fp64 oracle, the one-sided kernel and the compiler-scheduled pair-once kernel
     (rows_per_lane 4 keeps it)."""
     rng = np.random.default_rng(n + L)

@@ -31,6 +31,6 @@ for n in sizes:
             t0 = time.perf_counter()
             s.step_n(K, 1e-3, 1e-3)
             torch.cuda.synchronize()
-            kernel = "" if not (pps and mode == "pair_once") else " (compiler-scheduled kernel)" if rpl else " (eight-row loop)"
+            kernel = "" if not (pps and mode == "pair_once") else " (compiler-scheduled kernel)" if rpl else " (hand-scheduled loop)"
             print(f"N={n:8d} {mode:9s} per-particle softening {str(pps):5s}: {(time.perf_counter() - t0) / K * 1e3:9.3f} ms/step{kernel}",
                   flush=True)
