@@ -357,7 +357,9 @@ def main():
     ap.add_argument("--no-extra-legs", "--no-pair-once", dest="no_extra_legs", action="store_true",
                     help="skip the extra legs (the other force mode, the reference's N = 20000, the peer-copy leg)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL, the product path); gloo only to rehearse the multi-rank flow on one GPU")
+                    help="backend of the torch.distributed process group, which only carries the RCCL id and the final "
+                         "reductions of this script (gloo = NBODY_RENDEZVOUS=gloo: rehearsals with several ranks on one GPU); "
+                         "every per-step exchange is the library's own RCCL call")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
     mode = "pair_once" if args.force_mode == "symmetric" else args.force_mode
@@ -378,7 +380,6 @@ def main():
     import torch
     import torch.distributed as dist
     import n_body_problem_amd as nb
-    from n_body_problem_amd.sharded import sharded_system
     from n_body_problem_amd.multi import MultiGpuSystem
 
     if not torch.cuda.is_available():
@@ -392,9 +393,9 @@ def main():
     # NBODY_RENDEZVOUS=gloo: the product branch below (library-owned exchange, one rank per process) with the process
     # group on gloo -- for rehearsing it where real RCCL cannot run (several ranks on one GPU, the library linked with the
     # RCCL test double of tests/fake_rccl: NBODY_AMD_LIBRARY).  The driver's runs never set it.
-    gloo_rendezvous = os.environ.get("NBODY_RENDEZVOUS") == "gloo"
+    gloo_rendezvous = os.environ.get("NBODY_RENDEZVOUS") == "gloo" or args.backend == "gloo"
     if distributed:
-        if args.backend == "nccl" and not gloo_rendezvous:
+        if not gloo_rendezvous:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
@@ -414,12 +415,9 @@ def main():
                                     body_order=args.body_order)
             kernels = system.kernels
         else:
-            # nccl backend: MultiGpuSystem, the exchange inside the library; gloo: the host-staged rehearsal harness
-            if args.backend == "nccl":
-                system = MultiGpuSystem.from_torch_distributed(n, local_rank, exchange=args.exchange, force_mode=mode,
-                                                               body_order=args.body_order)
-            else:
-                system = sharded_system(n, device=local_rank, exchange=args.exchange, force_mode=mode, body_order="given")
+            # one rank per process, the exchange inside the library (the process group only carries the RCCL id)
+            system = MultiGpuSystem.from_torch_distributed(n, local_rank, exchange=args.exchange, force_mode=mode,
+                                                           body_order=args.body_order, create_timeout=args.exchange_timeout)
             kernels = system.kernels
         library_exchange = isinstance(system, MultiGpuSystem)
         rccl_ranks = system.info()["rccl_ranks"] if library_exchange else None
@@ -524,7 +522,7 @@ def main():
                        "exchange": args.exchange if world > 1 else None,
                        "backend": ("peer_copy (one process, hipMemcpyPeerAsync; secondary measurement)" if one_process else
                                    "rccl calls of the loaded library, process group on gloo (rehearsal)" if gloo_rendezvous else
-                                   "rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+                                   "rccl") if world > 1 else None,
                        "exchange_owner": ("library (nbody_multi_*, csrc/nbody_multi.hip)" if library_exchange else
                                           "torch.distributed rehearsal harness") if world > 1 else None,
                        "exchange_timeout_s": args.exchange_timeout if library_exchange else None,
@@ -573,7 +571,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     system.close()
-    if out is not None and distributed and args.backend == "nccl" and not args.no_extra_legs:
+    if out is not None and distributed and not gloo_rendezvous and not args.no_extra_legs:
         out["peer_copy_leg"] = peer_copy_leg(args)      # a child process, after this rank has let go of its GPU objects
     if out is not None:
         print(json.dumps(out), flush=True)

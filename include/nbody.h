@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 4
+#define NBODY_ABI_VERSION 5
 #define NBODY_MIN_SOFTENING 1.0e-9f
 
 typedef struct nbody_ctx nbody_ctx;
@@ -276,8 +276,10 @@ int nbody_upload_particle_softening(nbody_ctx *ctx, const float *h_eps);
 /* Kernel selection for experiments and A/B measurement: rows per lane (1, 2, 4 or 8; 0 = default: 4, the kernel with the
  * hand-allocated, packed-fp32 inner loop, in 1024-row workgroups where those fill the chip and in one-wave workgroups of 256
  * rows below that; 41 forces the one-wave form, 40 = the loop with one row per instruction, -4 = four rows with the
- * compiler-allocated loop).  In the pair-once mode 4 selects the four-row loops, 8 the eight-row ones.  In the one-sided
- * mode it never changes a result bit. */
+ * compiler-allocated loop).  In the one-sided mode it never changes a result bit.  In the pair-once mode: 0 or 8 = the
+ * eight-row loops on every tile of splits of whole 1024 bodies (the default), 4 = the packed four-row loops everywhere, 2 =
+ * round 2's arrangement (eight rows on equal-mass tiles only, in a four-waves-per-SIMD kernel), 1 = the one-column loops
+ * (what the environment switches of rounds 1-3 selected; the association of the sums follows the rows per wave). */
 int nbody_set_rows_per_lane(nbody_ctx *ctx, int rows_per_lane);
 
 /* Equal-mass splits (on by default).  Before every force launch an O(N) pass notes, per split, whether all its bodies
@@ -330,10 +332,12 @@ int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);
  * Process models: nbody_multi_create -- every rank in this process, driven from the calling host thread (RCCL calls of
  * the local ranks fused with ncclGroupStart/End); nbody_multi_create_rank -- one rank per process (the launch model of
  * torchrun / mpirun): rank 0 calls nbody_multi_unique_id and the caller hands the 128 bytes to every rank by any
- * channel it has.  Failure detection: RCCL's asynchronous error state is polled after every step and inside every
- * wait; nbody_multi_step_n keeps the host at most four steps ahead of the device, so no wait covers more than four steps,
- * and a wait longer than the timeout (default 600 s, NBODY_EXCHANGE_TIMEOUT_S or nbody_multi_set_timeout) aborts the
- * communicators and returns NBODY_ERR_DEVICE instead of hanging on a dead peer. */
+ * channel it has.  Failure detection: the communicators are non-blocking (ncclCommInitRankConfig, blocking = 0), so their
+ * creation -- the bootstrap, where a job with a missing rank hangs first -- and every RCCL call are polled under the timeout;
+ * RCCL's asynchronous error state is polled after every step and inside every wait; nbody_multi_step_n keeps the host at most
+ * four steps ahead of the device, so no wait covers more than four steps; a wait longer than the timeout (default 600 s; the
+ * environment variable NBODY_EXCHANGE_TIMEOUT_S -- the only one the library reads --, nbody_multi_config.create_timeout_s or
+ * nbody_multi_set_timeout) aborts the communicators and returns NBODY_ERR_DEVICE instead of hanging on a dead peer. */
 typedef struct nbody_multi nbody_multi;
 #define NBODY_UNIQUE_ID_BYTES 128
 enum { NBODY_EXCHANGE_ALLGATHER = 0, /* one ncclAllGather per step */
@@ -352,7 +356,8 @@ typedef struct nbody_multi_config {
     int body_order;    /* NBODY_ORDER_GIVEN | NBODY_ORDER_MORTON: nbody_multi_set_state stores the bodies in nbody_morton_order
                           of the positions it is given (the same on every rank), nbody_multi_download and
                           nbody_multi_set_particle_softening speak the caller's order; nbody_multi_order reads the permutation */
-    int reserved;      /* 0 */
+    int create_timeout_s; /* seconds the creation of the communicators and every later wait may take; 0 = the default
+                             (600 s, or NBODY_EXCHANGE_TIMEOUT_S); nbody_multi_set_timeout changes it for the waits that follow */
 } nbody_multi_config;
 
 /* Pure host functions (no device needed): the padded size and rows per rank, and hop `hop` (1..P-1) of the ring. */

@@ -1,8 +1,8 @@
 """MI355X-native all-pairs N-body step: drop-in for the step path of ctbfl/N_body_problem.
 
 Layout: ``csrc/`` hand-written HIP kernels (gfx950) + the C ABI of ``include/nbody.h``;
-``system.py`` the host-side mirror of the reference's step interface; ``sharded.py`` rows
-sharded over the GPUs of one node; ``initial_conditions.py`` seeded synthetic inputs.
+``system.py`` the host-side mirror of the reference's step interface; ``multi.py`` rows
+sharded over the GPUs of one node (the exchange inside the library); ``initial_conditions.py`` seeded synthetic inputs.
 """
 from .initial_conditions import plummer, uniform_cube, pad_reference_style, padded_count, CONFIG_SEED  # noqa: F401
 from ._lib import NBodyError  # noqa: F401

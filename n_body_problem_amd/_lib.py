@@ -126,7 +126,7 @@ _PROTOTYPES = {
 class MultiConfig(ctypes.Structure):
     """``nbody_multi_config`` of include/nbody.h."""
     _fields_ = [("n_bodies", c_int64), ("split_len", c_int64), ("force_mode", c_int), ("integrator", c_int),
-                ("exchange", c_int), ("transport", c_int), ("body_order", c_int), ("reserved", c_int)]
+                ("exchange", c_int), ("transport", c_int), ("body_order", c_int), ("create_timeout_s", c_int)]
 
 _lib = None
 

@@ -77,7 +77,6 @@ struct nbody_ctx {
     } graph_key;
     int graph_replay = -1;  // -1: automatic (systems of at most kGraphAutoBodies bodies), 0: off, 1: on
     hipStream_t aux_stream = nullptr;  // pair-once mode: the diagonal-tile launch runs here, beside the tile launch
-    hipStream_t tile_stream2 = nullptr;  // NBODY_SYM_TILE_STREAMS=2 (experiment): odd summation parts' tiles, lowest priority
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_graph_in = nullptr, ev_graph_out = nullptr;
     hipEvent_t ev_flags = nullptr;  // the step's equal-mass flags have been written (a later force call may run on another stream)
     bool flags_valid = false;       // split_mass holds the flags of the positions of this step (launch_split_mass has run since the
@@ -477,7 +476,6 @@ int nbody_destroy(nbody_ctx *c)
     if (c->ev_graph_in) (void)hipEventDestroy(c->ev_graph_in);
     if (c->ev_graph_out) (void)hipEventDestroy(c->ev_graph_out);
     if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
-    if (c->tile_stream2) (void)hipStreamDestroy(c->tile_stream2);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1077,11 +1075,10 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             // distance d has column split (R + d) mod S.  Blocks of 8 row splits x 8 distances touch 23 splits' bodies
             // instead of 128; workgroups are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md), so block k's tiles
             // take the launch slots congruent to k mod 8 and meet in one XCD's L2.
-            static const bool blocked = !(getenv("NBODY_SYM_TILE_ORDER") && atoi(getenv("NBODY_SYM_TILE_ORDER")) == 0);
-            const int B = blocked ? 8 : S;
+            const int B = 8;
             auto list_rows = [&](int r_lo, int r_hi) {  // the tiles with a row split in [r_lo, r_hi), in launch order
                 std::vector<int2> tiles;
-                std::vector<std::vector<int2>> per_xcd(blocked ? 8 : 1);
+                std::vector<std::vector<int2>> per_xcd(8);
                 int k = 0;
                 for (int Rb = r_lo; Rb < r_hi; Rb += B)
                     for (int db = 1; db <= S / 2; db += B, ++k)
@@ -1113,9 +1110,9 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 // 4 parts of 3 + 3 + 1 + 1 groups hold two slots of three groups = 3/4 of the pass; 8 equal parts a quarter
                 K = pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 1 : 0.75 * pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 4 : 8;
             }
-            // below 32768 tiles (N = 2^18) an extra launch costs more than the summation it hides; the variable is for tests
-            const char *min_env = getenv("NBODY_SYM_PARTS_MIN_TILES");
-            const int64_t min_tiles = min_env ? atoll(min_env) : 32768;
+            // below 32768 tiles (N = 2^18) an extra launch costs more than the summation it hides: the automatic choice takes
+            // one part there (an explicit nbody_set_summation_parts is honoured at every size)
+            const int64_t min_tiles = c->sum_parts == 0 ? 32768 : 0;
             if (!whole || (int64_t)S * S / 2 < min_tiles || n_groups < 2)
                 K = 1;
             else if (K > 2 && n_groups % K != 0)
@@ -1197,15 +1194,12 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         // kernel holds the equal-mass loop (S8) and the loop for arbitrary masses (S9), allocated for three waves per SIMD, which
         // costs the equal-mass loop 0.1 % against its own four-waves kernel (144.33 / 144.39 against 144.17 / 144.19 ms per
         // N = 2^20 pass, profiles/r03_ab_packed3_equal_mass.txt) and gives every tile with arbitrary masses the eight-row loop
-        // (164.0 against 176.2 ms with the four-row loop, profiles/r03_ab_general_mass_eight_rows.txt).  NBODY_SYM_PACKED=2:
-        // round 2's arrangement (equal-mass tiles eight rows in a four-waves kernel, the others four rows); 1: four rows per lane
-        // everywhere; 0: the one-column loops -- A/B measurement.  NBODY_SYM_GENERAL8=0: with the equal-mass path off, the
-        // four-row kernel.
-        static const int packed_env = getenv("NBODY_SYM_PACKED") ? atoi(getenv("NBODY_SYM_PACKED")) : 3;
-        sa.packed = c->rows_per_lane == 8 ? 3 : c->rows_per_lane == 4 ? 1 : packed_env;  // nbody_set_rows_per_lane: A/B in one process
-        static const bool general8 = !(getenv("NBODY_SYM_GENERAL8") && atoi(getenv("NBODY_SYM_GENERAL8")) == 0);
+        // (164.0 against 176.2 ms with the four-row loop, profiles/r03_ab_general_mass_eight_rows.txt).  The other arrangements
+        // stay reachable through nbody_set_rows_per_lane for A/B measurement in one process: 2 = round 2's (equal-mass tiles eight
+        // rows in a four-waves kernel, the others four rows), 4 = four rows per lane everywhere, 1 = the one-column loops.
+        sa.packed = c->rows_per_lane == 4 ? 1 : c->rows_per_lane == 2 ? 2 : c->rows_per_lane == 1 ? 0 : 3;
         if (sa.packed >= 2 && !c->equal_mass_path)
-            sa.packed = general8 ? 3 : 1;  // no tile can take the equal-mass loop
+            sa.packed = 3;  // no tile can take the equal-mass loop
         auto part_args = [&](const nbody_ctx::SymPart &p) {
             sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;
             sa.col_partials = c->col_partials + p.col_off;
@@ -1242,19 +1236,9 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         for (int p = 0; p < std::min(K, 2); ++p)
             if (int rc = diag_launch(p))
                 return rc;
-        // Experiment (NBODY_SYM_TILE_STREAMS=2): the odd parts' tile launches on a second stream of the lowest priority, not
-        // ordered behind the even parts': their first workgroups fill the tail of the launch before them.
-        static const bool two_tile_streams = getenv("NBODY_SYM_TILE_STREAMS") && atoi(getenv("NBODY_SYM_TILE_STREAMS")) == 2;
-        if (two_tile_streams && K > 1 && !c->tile_stream2) {
-            int least = 0, greatest = 0;
-            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->tile_stream2, hipStreamNonBlocking, least));
-        }
         for (int p = 0; p < K; ++p) {
             const nbody_ctx::SymPart &part = plan.parts[(size_t)p];
-            hipStream_t ts = two_tile_streams && (p & 1) ? c->tile_stream2 : c->stream;
-            if (ts != c->stream)
-                HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_fork, 0));  // the positions and the split masses are in place
+            hipStream_t ts = c->stream;
             if (K > 2 && p >= 2)
                 HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_red[(size_t)p - 2], 0));
             part_args(part);
@@ -1262,13 +1246,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches, ts, true);  // the dominant kernel alone
                 HIP_TRY(c, launch_forces_symmetric(sa, ts));
             }
-            if (p == K - 1) {
-                if (ts != c->stream) {  // the last part's sums are formed on the context's stream
-                    HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], ts));
-                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_tiles[(size_t)p], 0));
-                }
-                break;
-            }
+            if (p == K - 1)
+                break;  // the last part's sums are formed on the context's stream
             HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], ts));
             HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_tiles[(size_t)p], 0));
             {
@@ -1366,9 +1345,9 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
     {
         TimedLaunch t(c, &c->ev_update, &c->update_ms, &c->update_launches);
         // Small and mid-size systems (every row, the tiles in one part, nothing summed yet): one finishing kernel instead of
-        // column sums + row sums + update.  NBODY_SYM_FUSED_FINISH=0 switches it off, =N sets the largest split count it
-        // is used for (A/B measurement; the bits are the same either way).
-        static const int fused_max_splits = getenv("NBODY_SYM_FUSED_FINISH") ? atoi(getenv("NBODY_SYM_FUSED_FINISH")) : 320;
+        // column sums + row sums + update (up to 320 splits: -4 % per step at N = 32 768, nothing from 131 072 on,
+        // profiles/r03_ab_fused_finish.txt; the bits are the same either way).
+        constexpr int fused_max_splits = 320;
         if (c->force_mode == NBODY_FORCE_SYMMETRIC && c->row_lo == 0 && c->row_count == c->n_total && c->pending &&
             !c->sym_reduced && !c->sym_rows_summed && c->pending->g1 - c->pending->g0 == c->group_count &&
             c->pending->row_off == 0 && c->pending->col_off == 0 && c->n_splits <= fused_max_splits) {

@@ -14,13 +14,17 @@
 //
 // NBODY_EXCHANGE_RING spells the position all-gather out as P-1 ncclSend/ncclRecv hops with one event per hop; the
 // force launch of chunk (rank - h) starts as hop h lands.  Two process models, one code path: every rank in this
-// process (nbody_multi_create: ncclCommInitAll, collectives of the local ranks fused with ncclGroupStart/End), or one
-// rank per process (nbody_multi_create_rank: ncclCommInitRank with an id the caller distributes).
+// process (nbody_multi_create: one communicator per device from an id made here, collectives of the local ranks fused with
+// ncclGroupStart/End), or one rank per process (nbody_multi_create_rank: an id the caller distributes).
 // NBODY_TRANSPORT_PEER_COPY (single process only) moves the same slices with hipMemcpyPeerAsync instead of RCCL: RCCL
 // refuses two ranks on one device, so this is also how two shards on ONE GPU are tested against a single context.
 //
-// Failure detection: ncclCommGetAsyncError is polled after every step and inside every wait; a wait
-// that exceeds the timeout aborts the communicators and returns NBODY_ERR_DEVICE instead of hanging on a dead peer.
+// Failure detection: the communicators are NON-BLOCKING (ncclCommInitRankConfig, blocking = 0): creation and
+// every RCCL call return at once and the library polls ncclCommGetAsyncError under its timeout -- so a peer that never
+// arrives is reported by nbody_multi_create* itself (the bootstrap is the first thing that can hang), and nothing is recorded
+// on a stream behind an RCCL call before RCCL says the call has been enqueued.  The asynchronous error state is polled after
+// every step and inside every wait; a wait that exceeds the timeout aborts the communicators and returns NBODY_ERR_DEVICE
+// instead of hanging on a dead peer.
 //
 // Determinism: chunk boundaries are multiples of split_len (whole split groups in the pair-once mode), so the state is
 // bit-identical to one context on the same padded system for any world size, exchange mode or arrival order.
@@ -140,11 +144,30 @@ static int guarded(nbody_multi *m, F &&body)
             return mfail((m), e_ == hipErrorOutOfMemory ? NBODY_ERR_ALLOC : NBODY_ERR_DEVICE,                  \
                          std::string(#call) + ": " + hipGetErrorString(e_));                                   \
     } while (0)
+// A non-blocking communicator answers ncclInProgress where a blocking one would have blocked (ncclGroupEnd above all): the
+// call counts as made only once ncclCommGetAsyncError has left that state -- an event recorded on the stream before that
+// could land in front of the collective's kernel.  nccl_settle waits for it, bounded by the timeout.
+static int nccl_settle(nbody_multi *m, const char *what);
 #define MNCCL(m, call)                                                                                         \
     do {                                                                                                       \
         ncclResult_t r_ = (call);                                                                              \
-        if (r_ != ncclSuccess && r_ != ncclInProgress)                                                         \
+        if (r_ == ncclInProgress) {                                                                            \
+            int s_ = nccl_settle((m), #call);                                                                  \
+            if (s_ != NBODY_OK)                                                                                \
+                return s_;                                                                                     \
+        } else if (r_ != ncclSuccess)                                                                          \
             return mfail((m), NBODY_ERR_DEVICE, std::string(#call) + ": RCCL: " + ncclGetErrorString(r_));     \
+    } while (0)
+// The event edges of the RCCL branch, numbered: tools/edge_mutations.py builds the library with one of them left out
+// (-DNB_DROP_EDGE=k, never in the product) and checks that the multi-process tests over the RCCL test double turn red -- the
+// evidence that those tests can see a missing hipStreamWaitEvent (profiles/r04_edge_mutations.txt).
+#ifndef NB_DROP_EDGE
+#define NB_DROP_EDGE 0
+#endif
+#define EDGE(k, m, call)                                                                                       \
+    do {                                                                                                       \
+        if (NB_DROP_EDGE != (k))                                                                               \
+            MHIP((m), call);                                                                                   \
     } while (0)
 #define MCTX(m, r, call)                                                                                       \
     do {                                                                                                       \
@@ -257,12 +280,12 @@ static int setup_ranks(nbody_multi *m)
         MHIP(m, hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
         // The exchange's kernels (RCCL's, or the copy engine's fallbacks) must win CUs from a force launch that fills every
         // CU with 0.6 ms workgroups, and the complement launch waits for them: the communication stream gets the highest
-        // priority the device offers (NBODY_COMM_PRIORITY=0: the default priority, for A/B measurement).
+        // priority the device offers (at the default priority the column-sum exchange sat 35 ms behind another rank's force
+        // kernels on a shared GPU, at the highest 0.7 ms: profiles/r03_rehearsal_comm_priority_ab_two_ranks_one_gpu.txt).
         {
-            static const bool high = !(getenv("NBODY_COMM_PRIORITY") && atoi(getenv("NBODY_COMM_PRIORITY")) == 0);
             int least = 0, greatest = 0;
             MHIP(m, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            MHIP(m, hipStreamCreateWithPriority(&r.comm, hipStreamNonBlocking, high ? greatest : 0));
+            MHIP(m, hipStreamCreateWithPriority(&r.comm, hipStreamNonBlocking, greatest));
         }
         if (m->n_padded) {
             MHIP(m, hipMalloc((void **)&r.pos, sizeof(float) * 4 * (size_t)m->n_padded));
@@ -338,14 +361,102 @@ static int create_common(nbody_multi **out, const nbody_multi_config *cfg, int w
     m->n_padded = padded;
     m->chunk = chunk;
     m->split_len = split;
-    if (const char *t = getenv("NBODY_EXCHANGE_TIMEOUT_S"))
+    if (const char *t = getenv("NBODY_EXCHANGE_TIMEOUT_S"))  // the one environment variable the library reads (nbody.h)
         if (atof(t) > 0)
             m->timeout_s = atof(t);
+    if (cfg->create_timeout_s > 0)  // bounds the creation of the communicators too (nbody_multi_set_timeout comes too late for it)
+        m->timeout_s = (double)cfg->create_timeout_s;
     *made = m;
     return NBODY_OK;
 }
 
 extern "C" int nbody_multi_destroy(nbody_multi *m);
+static void abort_communicators(nbody_multi *m);
+
+// Every local communicator out of ncclInProgress: the call (creation, a collective, a group) has been made and, for a call
+// that takes a stream, enqueued.  An error state or a wait beyond the timeout aborts the communicators.
+static int nccl_settle(nbody_multi *m, const char *what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (Rank &r : m->ranks) {
+        if (!r.nccl)
+            continue;
+        for (;;) {
+            ncclResult_t state = ncclSuccess;
+            const ncclResult_t q = ncclCommGetAsyncError(r.nccl, &state);
+            if (q == ncclSuccess && state == ncclSuccess)
+                break;
+            if (q != ncclSuccess || state != ncclInProgress) {
+                const ncclResult_t bad = q != ncclSuccess ? q : state;
+                const std::string msg = std::string(what) + ": RCCL reported an error on rank " + std::to_string(r.rank) + ": " +
+                                        ncclGetErrorString(bad) + " (" + ncclGetLastError(r.nccl) + "); the communicators were aborted";
+                abort_communicators(m);
+                return mfail(m, NBODY_ERR_DEVICE, msg);
+            }
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > m->timeout_s) {
+                abort_communicators(m);
+                return mfail(m, NBODY_ERR_DEVICE, std::string(what) + ": timed out after " + std::to_string((int)waited) +
+                                                      " s inside RCCL (a peer rank never arrived or is stuck); the communicators were aborted");
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(++spins < 200 ? 5 : 200));
+        }
+    }
+    return NBODY_OK;
+}
+
+// One non-blocking communicator per local rank from the id (one process per GPU: one rank; every rank in this process: all of
+// them inside one group, what ncclCommInitAll does with blocking ones).  The bootstrap is where a job with a missing rank
+// hangs first: the wait for it is bounded like every other.
+static int init_communicators(nbody_multi *m, const ncclUniqueId &id)
+{
+    ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
+    config.blocking = 0;
+    const bool group = m->ranks.size() > 1;
+    if (group) {
+        ncclResult_t g = ncclGroupStart();
+        if (g != ncclSuccess)
+            return mfail(m, NBODY_ERR_DEVICE, std::string("ncclGroupStart: RCCL: ") + ncclGetErrorString(g));
+    }
+    ncclResult_t bad = ncclSuccess;
+    for (Rank &r : m->ranks) {
+        if (hipSetDevice(r.device) != hipSuccess) {
+            bad = ncclUnhandledCudaError;
+            break;
+        }
+        const ncclResult_t q = ncclCommInitRankConfig(&r.nccl, m->world, id, r.rank, &config);
+        if (q != ncclSuccess && q != ncclInProgress) {
+            bad = q;
+            r.nccl = nullptr;
+            break;
+        }
+    }
+    if (group) {
+        const ncclResult_t g = ncclGroupEnd();
+        if (bad == ncclSuccess && g != ncclSuccess && g != ncclInProgress)
+            bad = g;
+    }
+    if (bad != ncclSuccess) {
+        bool dup = false;
+        for (size_t i = 0; i < m->ranks.size(); ++i)
+            for (size_t j = 0; j < i; ++j)
+                dup |= m->ranks[i].device == m->ranks[j].device;
+        abort_communicators(m);
+        return mfail(m, NBODY_ERR_DEVICE, std::string("ncclCommInitRankConfig: RCCL: ") + ncclGetErrorString(bad) +
+                                              (dup ? " (two ranks on one device: NBODY_TRANSPORT_PEER_COPY serves those)" : ""));
+    }
+    int rc = nccl_settle(m, "creating the RCCL communicators");
+    if (rc != NBODY_OK) {
+        bool dup = false;
+        for (size_t i = 0; i < m->ranks.size(); ++i)
+            for (size_t j = 0; j < i; ++j)
+                dup |= m->ranks[i].device == m->ranks[j].device;
+        if (dup)
+            m->err += " (two ranks on one device: NBODY_TRANSPORT_PEER_COPY serves those)";
+    }
+    return rc;
+}
 
 extern "C" int nbody_multi_create(nbody_multi **out, const nbody_multi_config *cfg, const int *devices, int n_devices)
 {
@@ -355,16 +466,9 @@ extern "C" int nbody_multi_create(nbody_multi **out, const nbody_multi_config *c
     int rc = create_common(out, cfg, n_devices, &m);
     if (rc != NBODY_OK)
         return rc;
-    // NBODY_RCCL_ALLOW_SHARED_DEVICE: tests that link the RCCL test double (tests/fake_rccl) run this path with every rank on
-    // one device; real RCCL reports duplicate devices itself
-    if (rccl(m) && !getenv("NBODY_RCCL_ALLOW_SHARED_DEVICE"))
-        for (int i = 0; i < n_devices; ++i)
-            for (int j = 0; j < i; ++j)
-                if (devices[i] == devices[j]) {
-                    delete m;
-                    return mfail(nullptr, NBODY_ERR_INVALID, "nbody_multi_create: RCCL needs distinct devices (two ranks on one "
-                                                             "device: NBODY_TRANSPORT_PEER_COPY)");
-                }
+    // two ranks on one device: RCCL itself refuses them ("invalid usage", profiles/r02_rccl_two_ranks_one_device_refused.txt)
+    // and init_communicators passes that on with a hint; the library has no opinion of its own (the RCCL test double of
+    // tests/fake_rccl serves any devices)
     m->ranks.resize((size_t)n_devices);
     for (int i = 0; i < n_devices; ++i) {
         m->ranks[(size_t)i].rank = i;
@@ -372,13 +476,10 @@ extern "C" int nbody_multi_create(nbody_multi **out, const nbody_multi_config *c
     }
     rc = setup_ranks(m);
     if (rc == NBODY_OK && rccl(m)) {
-        std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
-        ncclResult_t r = ncclCommInitAll(comms.data(), n_devices, devices);
-        if (r != ncclSuccess)
-            rc = mfail(m, NBODY_ERR_DEVICE, std::string("ncclCommInitAll: RCCL: ") + ncclGetErrorString(r));
-        else
-            for (int i = 0; i < n_devices; ++i)
-                m->ranks[(size_t)i].nccl = comms[(size_t)i];
+        ncclUniqueId id;
+        ncclResult_t r = ncclGetUniqueId(&id);
+        rc = r != ncclSuccess ? mfail(m, NBODY_ERR_DEVICE, std::string("ncclGetUniqueId: RCCL: ") + ncclGetErrorString(r))
+                              : init_communicators(m, id);
     }
     if (rc != NBODY_OK) {
         g_multi_create_error = m->err;
@@ -412,13 +513,7 @@ extern "C" int nbody_multi_create_rank(nbody_multi **out, const nbody_multi_conf
     if (rc == NBODY_OK && rccl(m)) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id128, sizeof id);
-        if (hipSetDevice(device) != hipSuccess)
-            rc = mfail(m, NBODY_ERR_DEVICE, "hipSetDevice failed");
-        else {
-            ncclResult_t r = ncclCommInitRank(&m->ranks[0].nccl, world_size, id, rank);
-            if (r != ncclSuccess)
-                rc = mfail(m, NBODY_ERR_DEVICE, std::string("ncclCommInitRank: RCCL: ") + ncclGetErrorString(r));
-        }
+        rc = init_communicators(m, id);
     }
     if (rc != NBODY_OK) {
         g_multi_create_error = m->err;
@@ -513,7 +608,6 @@ extern "C" int nbody_multi_destroy(nbody_multi *m)
 // ---- waiting, with failure detection ---------------------------------------------------------------------------------
 
 static int timed_out(nbody_multi *m, double waited);
-static void abort_communicators(nbody_multi *m);
 
 static int poll_async_errors(nbody_multi *m)
 {
@@ -741,7 +835,7 @@ static int start_allgather(nbody_multi *m, Channel &ch, RankBuffer buf, size_t s
         Rank &r = m->ranks[i];
         MHIP(m, hipSetDevice(r.device));
         if (rccl(m)) {  // the collective itself orders the ranks: nobody's slice is written before everybody has entered
-            MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[i], 0));
+            EDGE(1, m, hipStreamWaitEvent(r.comm, ch.ready[i], 0));
         } else {        // peer copies write into the others' buffers: wait until they have stopped reading them
             for (size_t j = 0; j < nl; ++j)
                 MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[j], 0));
@@ -786,7 +880,7 @@ static int wait_allgather(nbody_multi *m, Channel &ch, size_t i, hipStream_t str
     Rank &r = m->ranks[i];
     MHIP(m, hipSetDevice(r.device));
     if (rccl(m)) {
-        MHIP(m, hipStreamWaitEvent(stream, ch.done[i], 0));
+        EDGE(2, m, hipStreamWaitEvent(stream, ch.done[i], 0));
     } else {
         for (size_t j = 0; j < m->ranks.size(); ++j)
             MHIP(m, hipStreamWaitEvent(stream, ch.done[j], 0));
@@ -811,7 +905,7 @@ static int start_ring(nbody_multi *m)
         Rank &r = m->ranks[i];
         MHIP(m, hipSetDevice(r.device));
         if (rccl(m)) {
-            MHIP(m, hipStreamWaitEvent(r.comm, m->ch_pos.ready[i], 0));
+            EDGE(5, m, hipStreamWaitEvent(r.comm, m->ch_pos.ready[i], 0));
         } else {
             for (size_t j = 0; j < nl; ++j)
                 MHIP(m, hipStreamWaitEvent(r.comm, m->ch_pos.ready[j], 0));
@@ -869,7 +963,10 @@ static int wait_ring_hop(nbody_multi *m, size_t i, int h, hipStream_t stream)
     const size_t nl = m->ranks.size();
     MHIP(m, hipSetDevice(r.device));
     hipEvent_t e = rccl(m) ? r.ev_hop[(size_t)h] : m->ranks[(i + nl - 1) % nl].ev_hop[(size_t)h];
-    MHIP(m, hipStreamWaitEvent(stream, e, 0));
+    if (rccl(m))
+        EDGE(3, m, hipStreamWaitEvent(stream, e, 0));
+    else
+        MHIP(m, hipStreamWaitEvent(stream, e, 0));
     return NBODY_OK;
 }
 
@@ -920,7 +1017,7 @@ static int forces_all_columns(nbody_multi *m, float softening)
         // the next writer of the rank's own rows (the update behind these launches) follows the rank's own sends as well
         for (size_t i = 0; i < nl; ++i) {
             MHIP(m, hipSetDevice(m->ranks[i].device));
-            MHIP(m, hipStreamWaitEvent(m->ranks[i].compute, m->ch_pos.done[i], 0));
+            EDGE(4, m, hipStreamWaitEvent(m->ranks[i].compute, m->ch_pos.done[i], 0));
         }
         m->exchange_in_flight = false;
         return NBODY_OK;
@@ -968,7 +1065,7 @@ static int exchange_column_sums(nbody_multi *m)
         Rank &r = m->ranks[i];
         MHIP(m, hipSetDevice(r.device));
         if (rccl(m)) {  // a segment is written once its owner has posted the receive, behind its own `ready`
-            MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[i], 0));
+            EDGE(6, m, hipStreamWaitEvent(r.comm, ch.ready[i], 0));
         } else {        // peer copies write into the others' buffers: wait until they have stopped reading them
             for (size_t j = 0; j < nl; ++j)
                 MHIP(m, hipStreamWaitEvent(r.comm, ch.ready[j], 0));

@@ -1194,17 +1194,9 @@ static hipError_t sym_launch(K kernel, int blocks, int waves, size_t lds, const 
     return hipGetLastError();
 }
 
-// NBODY_SYM_LDS_PAD (bytes, experiments only): unused LDS per workgroup, to lower the number of workgroups a CU holds
-static size_t sym_lds_pad()
-{
-    static const size_t pad = getenv("NBODY_SYM_LDS_PAD") ? (size_t)atol(getenv("NBODY_SYM_LDS_PAD")) : 0;
-    return pad;
-}
-
 static size_t sym_lds_bytes_for(int waves, int split_len)
 {
-    return (size_t)waves * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + (size_t)waves * 128 * sizeof(float) +
-           sym_lds_pad();
+    return (size_t)waves * kSymStageFloatsPerWave * sizeof(float) + (size_t)split_len * 12 + (size_t)waves * 128 * sizeof(float);
 }
 
 template <int W>

@@ -74,18 +74,21 @@ class MultiGpuSystem:
 
     def __init__(self, num_bodies: int, devices: Optional[Sequence[int]] = None, force_mode: str = "one_sided",
                  integrator: str = "kick_drift", exchange: str = "allgather", transport: str = "rccl", split_len: int = 0,
-                 body_order: str = "given",
+                 body_order: str = "given", create_timeout: float = 0.0,
                  _rank: Optional[int] = None, _world_size: Optional[int] = None, _unique_id: Optional[bytes] = None):
         if body_order not in _system.BODY_ORDERS:
             raise ValueError(f"body_order must be one of {_system.BODY_ORDERS}")
         self.body_order = body_order   # "morton": the library stores the state in nbody_morton_order, download() undoes it
+        # create_timeout (seconds, rounded up; 0 = the library's default): the communicators are non-blocking and their creation
+        # is polled under it -- a rank that never arrives makes the constructor raise instead of hanging in RCCL's bootstrap
         self._m = ctypes.c_void_p(None)
         self._lib = _lib.load()
         self.num_bodies = int(num_bodies)
         self.force_mode = "pair_once" if force_mode == "symmetric" else force_mode
         self.integrator, self.exchange, self.transport = integrator, exchange, transport
         cfg = _lib.MultiConfig(self.num_bodies, int(split_len), FORCE_MODES[force_mode], INTEGRATORS[integrator],
-                               EXCHANGES[exchange], TRANSPORTS[transport], _system.BODY_ORDERS.index(body_order), 0)
+                               EXCHANGES[exchange], TRANSPORTS[transport], _system.BODY_ORDERS.index(body_order),
+                               int(-(-float(create_timeout) // 1)) if create_timeout and create_timeout > 0 else 0)
         m = ctypes.c_void_p(None)
         if _rank is None:
             devs = list(devices if devices is not None else [0])
@@ -286,3 +289,11 @@ class MultiGpuSystem:
         out = (ctypes.c_uint64 * 2)()
         _check(self._lib.nbody_multi_replica_checksums(self._m, out), self._m)
         return int(out[0]) == int(out[1])
+
+
+def sharded_system(num_bodies: int, device: int = 0, group=None, exchange: str = "allgather", force_mode: str = "one_sided",
+                   integrator: str = "kick_drift", split_len: int = 0, body_order: str = "given") -> MultiGpuSystem:
+    """The sharded system of this process's rank: one rank per process when a ``torch.distributed`` process group exists
+    (whatever its backend: it only carries the RCCL id), a single-rank system otherwise.  The exchange is the library's."""
+    return MultiGpuSystem.from_torch_distributed(num_bodies, device, group=group, exchange=exchange, force_mode=force_mode,
+                                                 integrator=integrator, split_len=split_len, body_order=body_order)

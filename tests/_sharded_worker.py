@@ -126,7 +126,7 @@ class PairOnceOracleKernels(OracleKernels):
         return self.colparts[lo:lo + cnt]
 
     def forces(self, col_lo, col_count, softening, positions=None):
-        from n_body_problem_amd.sharded import sym_rows_side
+        from sharded_harness import sym_rows_side
         pos = self.positions.numpy()
         self.calls.append(("range", col_lo, col_count))
         own = range(self.row_lo // self.L, (self.row_lo + self.rows) // self.L)
@@ -144,7 +144,7 @@ class PairOnceOracleKernels(OracleKernels):
         self.reduced = False
 
     def sym_reduce(self):
-        from n_body_problem_amd.sharded import sym_rows_side
+        from sharded_harness import sym_rows_side
         assert sorted(self.partials) == list(range(self.n_splits)), "a split is missing"
         lo, cnt, gs = self.sym_groups()
         cp = self.colparts.numpy()
@@ -158,7 +158,7 @@ class PairOnceOracleKernels(OracleKernels):
         self.reduced = True
 
     def _reduce(self):
-        from n_body_problem_amd.sharded import sym_rows_side
+        from sharded_harness import sym_rows_side
         assert self.reduced, "sym_reduce (and the exchange) must precede the update"
         cp = self.colparts.numpy()
         acc = np.zeros((self.rows, 3), dtype=np.float32)
@@ -184,7 +184,7 @@ def run_rank(rank, world_size, port, exchange, n, split_len, steps, out_dir, int
              force_mode="one_sided"):
     import torch.distributed as dist
     from n_body_problem_amd import initial_conditions as ic
-    from n_body_problem_amd.sharded import ShardedNBodySystem
+    from sharded_harness import ShardedNBodySystem
     if world_size > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
     try:
@@ -216,7 +216,7 @@ def run_rank_gpu(rank, world_size, port, exchange, n, steps, out_dir, integrator
     import torch
     import torch.distributed as dist
     from n_body_problem_amd import initial_conditions as ic
-    from n_body_problem_amd.sharded import ShardedNBodySystem
+    from sharded_harness import ShardedNBodySystem
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
     try:

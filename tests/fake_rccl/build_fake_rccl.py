@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libnbody_amd_fake_rccl.so")
-SRC = os.path.join(HERE, "fake_rccl.cpp")
+SRC = os.path.join(HERE, "fake_rccl.hip")
 
 
 def build(force: bool = False) -> str:
@@ -27,7 +27,7 @@ def build(force: bool = False) -> str:
         return LIB
     hipcc = product.hipcc()
     fake_obj = os.path.join(objdir, "fake_rccl.o")
-    for cmd in ([hipcc, "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", SRC, "-o", fake_obj],
+    for cmd in ([hipcc, "-O2", "-std=c++17", "-fPIC", "-Wall", f"--offload-arch={product.ARCH}", "-c", SRC, "-o", fake_obj],
                 [hipcc, "-shared", "-fPIC", f"--offload-arch={product.ARCH}", *objs, fake_obj, "-Wl,-Bsymbolic", "-lrt", "-lpthread",
                  "-o", LIB]):
         res = subprocess.run(cmd, capture_output=True, text=True)
@@ -55,6 +55,25 @@ def build_host(force: bool = False) -> str:
     return HOST
 
 
+PROBE = os.path.join(ROOT, "tests", "rccl_probe", "rccl_nonblocking_probe")
+
+
+def build_probe(force: bool = False) -> str:
+    """tests/rccl_probe: the library's calling protocol on non-blocking communicators against the REAL librccl (one rank)."""
+    sys.path.insert(0, ROOT)
+    from n_body_problem_amd import build as product
+    src = PROBE + ".hip"
+    if not force and os.path.exists(PROBE) and os.path.getmtime(src) <= os.path.getmtime(PROBE):
+        return PROBE
+    cmd = [product.hipcc(), "-O2", "-std=c++17", "-Wno-unused-value", f"--offload-arch={product.ARCH}", src, "-L/opt/rocm/lib",
+           "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", PROBE]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building the RCCL protocol probe failed:\n" + res.stderr[-4000:])
+    return PROBE
+
+
 if __name__ == "__main__":
     print(build(force=True))
     print(build_host(force=True))
+    print(build_probe(force=True))

@@ -1,11 +1,11 @@
-"""Rows sharded over several ranks with the exchange carried by ``torch.distributed`` -- the REHEARSAL harness.
+"""TEST INFRASTRUCTURE (not part of the product package): rows sharded over several ranks with the exchange carried by
+``torch.distributed`` -- the REHEARSAL harness.
 
 The product's multi-GPU step lives behind the C ABI (``nbody_multi_*``, csrc/nbody_multi.hip, Python view
 :class:`n_body_problem_amd.multi.MultiGpuSystem`): RCCL all-gather / ring inside the library, one process per GPU or
-all GPUs in one process.  :func:`sharded_system` returns that object whenever the process group's backend is ``nccl``
-(= RCCL) or there is no process group.
+all GPUs in one process (``n_body_problem_amd.multi.sharded_system``).
 
-What stays here is the same step spelled out in Python over ``torch.distributed`` with a host-staged backend (gloo),
+What lives here is the same step spelled out in Python over ``torch.distributed`` with a host-staged backend (gloo),
 for the two situations RCCL cannot serve: several ranks sharing ONE GPU (RCCL refuses duplicate devices) and ranks
 without any GPU, where ``kernels_factory`` injects a CPU stand-in for the kernels (tests/_sharded_worker.py) so that
 the sharding, the pair-once row/column/group data flow and both exchange schedules are checked under ``gloo`` with
@@ -23,7 +23,7 @@ from typing import Callable, Optional
 
 import numpy as np
 
-from . import system as _system
+from n_body_problem_amd import system as _system
 
 
 def shard_geometry(num_bodies: int, world_size: int, split_len: int):
@@ -319,19 +319,3 @@ class ShardedNBodySystem:
         self._refresh()
         if hasattr(self.kernels, "close"):
             self.kernels.close()
-
-
-def sharded_system(num_bodies: int, device: int = 0, group=None, exchange: str = "allgather", force_mode: str = "one_sided",
-                   integrator: str = "kick_drift", split_len: int = 0, body_order: str = "given"):
-    """The sharded system of this process's rank: the library-owned RCCL exchange (``MultiGpuSystem``) when the process
-    group's backend is ``nccl`` or there is no process group, the host-staged rehearsal harness otherwise (gloo)."""
-    import torch.distributed as dist
-    distributed = dist.is_available() and dist.is_initialized()
-    if not distributed or dist.get_backend(group) == "nccl":
-        from .multi import MultiGpuSystem
-        return MultiGpuSystem.from_torch_distributed(num_bodies, device, group=group, exchange=exchange, force_mode=force_mode,
-                                                     integrator=integrator, split_len=split_len, body_order=body_order)
-    if body_order != "given":
-        raise ValueError("the rehearsal harness keeps the caller's body order")
-    return ShardedNBodySystem(num_bodies, group=group, device=device, exchange=exchange, force_mode=force_mode,
-                              integrator=integrator, split_len=split_len)

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.nbody_abi_version() == 4           # 4: device-side body order, nbody_create_auto, NBODY_FORCE_AUTO, multi timing
+    assert lib.nbody_abi_version() == 5           # 5: non-blocking communicators (nbody_multi_config.create_timeout_s); 4: device-side body order, nbody_create_auto, NBODY_FORCE_AUTO, multi timing
     assert lib.nbody_status_string(0) == b"ok"
     for s in range(-5, 0):
         assert lib.nbody_status_string(s) not in (b"ok", b"unknown status")
@@ -98,6 +98,27 @@ def test_product_package_never_imports_the_oracle():
                 assert "nbody_oracle" not in text, f
 
 
+def test_the_library_reads_one_documented_environment_variable_and_the_package_ships_no_rehearsal_harness():
+    """Behaviour of a drop-in library is a function of its ABI: the only getenv left in the product's
+    sources is NBODY_EXCHANGE_TIMEOUT_S (documented in include/nbody.h beside nbody_multi_set_timeout); the A/B switches of
+    rounds 1-3 are gone or behind nbody_set_rows_per_lane / nbody_set_summation_parts; the torch.distributed rehearsal
+    harness lives under tests/."""
+    names = set()
+    for sub in ("n_body_problem_amd/csrc", "include", "host"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".hip", ".h", ".hpp", ".cpp")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    names |= set(re.findall(r'getenv\(\s*"([A-Z0-9_]+)"', text))
+                    if sub != "host":
+                        assert len(re.findall(r"\bgetenv\s*\(", text)) == len(re.findall(r'getenv\(\s*"NBODY_EXCHANGE_TIMEOUT_S"', text)), f
+    assert "NBODY_EXCHANGE_TIMEOUT_S" in names
+    assert not [n for n in names if n.startswith("NBODY_") and n not in ("NBODY_EXCHANGE_TIMEOUT_S",)], names
+    assert "NBODY_EXCHANGE_TIMEOUT_S" in open(os.path.join(ROOT, "include", "nbody.h")).read()
+    assert not os.path.exists(os.path.join(ROOT, "n_body_problem_amd", "sharded.py"))
+    assert os.path.exists(os.path.join(ROOT, "tests", "sharded_harness.py"))
+
+
 def test_header_is_plain_c_and_the_integration_patch_compiles(tmp_path):
     """include/nbody.h must be usable from C (the boundary is a C ABI: no C++ in the header), and the call-site patch of
     INTEGRATION.md section 2 -- the functions a maintainer of the reference would write -- must compile and link against the
@@ -145,7 +166,7 @@ int main(void) {
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)          # no device needed: only host helpers are called
-    assert run.returncode == 0 and "abi 4, split 2048, pair-once from 32768 bodies" in run.stdout, run.stdout + run.stderr
+    assert run.returncode == 0 and "abi 5, split 2048, pair-once from 32768 bodies" in run.stdout, run.stdout + run.stderr
 
 
 def test_the_rccl_test_double_build_is_the_same_library_without_librccl():

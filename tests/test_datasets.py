@@ -116,8 +116,14 @@ def test_committed_k17hp_and_stars_fixtures(golden_dir):
     first = [float(x) for x in open(os.path.join(golden_dir, "stars_8192.dat")).readline().split()]
     assert p.shape == (8192, 4) and np.all(p[:, 3] == 1) and np.all(v[:, 3] == 0)
     assert np.allclose(p[0, :3], first[2::-1], rtol=1e-6) and np.allclose(v[0, :3], first[5:2:-1], rtol=1e-6)   # z y x order on disk
+    whole, wv = ds.read_any(os.path.join(golden_dir, "stars.dat"))        # load_data(3) at its real size (kernel.cu:996-1000)
+    assert whole.shape == (43802, 4) and np.all(whole[:, 3] == 1) and np.all(wv[:, 3] == 0) and ic.padded_count(43802) == 44033
+    assert np.array_equal(whole[:8192], p) and np.array_equal(wv[:8192], v)
+    assert hashlib.sha256(open(os.path.join(golden_dir, "stars.dat"), "rb").read()).hexdigest() == \
+        "836bb3b21b91c71343e49f612ff10c6e79091995d41d0f79df178dd4fd5b9556"
     if os.path.isdir(REF_DATA):
         sha = lambda f: hashlib.sha256(open(f, "rb").read()).hexdigest()
+        assert sha(os.path.join(golden_dir, "stars.dat")) == sha(os.path.join(REF_DATA, "stars.dat"))
         assert sha(os.path.join(golden_dir, "k17hp.snap")) == sha(os.path.join(REF_DATA, "k17hp.snap"))
         assert sha(os.path.join(golden_dir, "k17c.snap")) == sha(os.path.join(REF_DATA, "k17c.snap"))
         full, _ = ds.read_dat(os.path.join(REF_DATA, "stars.dat"))

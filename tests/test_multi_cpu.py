@@ -16,7 +16,8 @@ def free_port():
 
 
 def test_geometry_matches_the_rehearsal_harness_and_keeps_whole_groups():
-    from n_body_problem_amd import multi, sharded, system
+    import sharded_harness as sharded
+    from n_body_problem_amd import multi, system
     for n in (1, 1000, 20000, 65536, 1 << 20, (1 << 22) + 5):
         for world in (1, 2, 3, 4, 8):
             split = system.default_split_len(n)
@@ -37,7 +38,8 @@ def test_geometry_matches_the_rehearsal_harness_and_keeps_whole_groups():
 
 
 def test_ring_schedule_delivers_every_chunk_exactly_once():
-    from n_body_problem_amd import multi, sharded
+    import sharded_harness as sharded
+    from n_body_problem_amd import multi
     for P in (1, 2, 3, 4, 8):
         assert all(multi.ring_schedule(r, P) == sharded.ring_schedule(r, P) for r in range(P))
         have = {r: [r] for r in range(P)}

@@ -139,7 +139,7 @@ def test_rccl_leg_with_the_one_rank_this_box_has(oracle_mod):
 
 def test_from_torch_distributed_without_a_process_group_is_one_rank():
     import n_body_problem_amd as nb
-    from n_body_problem_amd.sharded import sharded_system
+    from n_body_problem_amd.multi import sharded_system
     from n_body_problem_amd.multi import MultiGpuSystem
     n = 5000
     pos, vel = nb.plummer(n, seed=5)
@@ -261,12 +261,45 @@ def test_headline_size_two_shards_on_one_gpu_equal_one_context(oracle_mod, force
     assert np.array_equal(p1[:, 3], pos[:, 3]) and np.all(v1[:, 3] == 0)
 
 
+@pytest.mark.parametrize("integrator", ["kick_drift", "kdk"])
+def test_config5_shape_thousand_steps_one_context_and_two_shards(integrator):
+    """BASELINE configs[4] in shape, at a size the GPU suite can afford: a long run (1000 steps) of a Plummer sphere in the
+    pair-once mode with the bodies along the Morton curve, the layout refreshed every 50 steps on the device, energy checked
+    at the end -- N = 2^17 instead of 2^22, as ONE rank and as TWO shards with the library-owned exchange: the same bits after
+    1000 steps (a run's bits depend on the refresh period, not on the rank count), |dE/E0| bounded, momentum conserved."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 1 << 17, 1000
+    pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[5])
+    out = {}
+    for world in (1, 2):
+        with MultiGpuSystem(n, devices=[0] * world, force_mode="pair_once", integrator=integrator, transport="peer_copy",
+                            body_order="morton") as m:
+            assert m.split_len == 1024 and m.n_padded == n
+            m.set_state(pos, vel)
+            m.set_reorder_period(50)
+            e0 = m.energy(EPS)
+            m.step_n(steps, DT, EPS)
+            e1, mom = m.energy(EPS), m.momentum()
+            assert m.replicas_identical()
+            out[world] = (*m.download(), e0, e1, mom)
+    p1, v1, e0, e1, mom = out[1]
+    p2, v2, e0b, e1b, _ = out[2]
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+    assert np.allclose(e0, e0b, rtol=1e-12) and np.allclose(e1, e1b, rtol=1e-12)
+    drift = abs(e1[2] - e0[2]) / abs(e0[2])
+    print(f"N = 2^17, 1000 steps, {integrator}, refresh every 50: |dE/E0| = {drift:.2e}, |p| = {np.abs(mom[:3]).max():.1e}")
+    assert drift < (2e-5 if integrator == "kdk" else 2e-4)
+    assert np.abs(mom[:3]).max() < 1e-5
+    assert np.abs(p1[:, :3] - pos[:, :3]).max() > 0.1                       # a unit of time: the bodies have moved
+
+
 def _one_rank_under_torch_nccl(rank, port, out_path):
     import torch
     import torch.distributed as dist
     import n_body_problem_amd as nb
     from n_body_problem_amd.multi import MultiGpuSystem
-    from n_body_problem_amd.sharded import sharded_system
+    from n_body_problem_amd.multi import sharded_system
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))

@@ -1,7 +1,10 @@
 """ONE RANK PER PROCESS -- the model the benchmark's ranks run under torchrun on a multi-GPU node (nbody_multi_create_rank,
 include/nbody.h) -- executed by 2-4 processes that share cuda:0.  Real RCCL refuses two ranks on one device, so these
-processes load a second build of the library in which the fifteen RCCL entry points are a test double that moves the bytes
-through shared memory (tests/fake_rccl; the product library always links the real librccl).  What this covers that the
+processes load a second build of the library in which the RCCL entry points are a test double (tests/fake_rccl; the product
+library always links the real librccl).  Since round 4 the double keeps RCCL's STREAM semantics -- calls return at once, the
+bytes move on the caller's stream behind what the caller ordered in front of them, other streams see the result only through
+the events the library records -- so a missing hipStreamWaitEvent in the library's exchange turns these tests red
+(tools/edge_mutations.py, profiles/r04_edge_mutations.txt), and its communicators are non-blocking like the product's.  What this covers that the
 single-process peer-copy tests cannot: every place where the library must tell a LOCAL index from a GLOBAL rank, the order
 of the collective calls each rank makes, the id hand-over, the collective download / diagnostics, and what a rank reports
 when a peer is gone.  The results must equal the single-process run of the same configuration bit for bit."""
@@ -112,7 +115,7 @@ def test_all_ranks_in_one_process_over_the_rccl_calls(fake_library, world, cfg):
     [...])).  All ranks on cuda:0 over the test double; equal to the peer-copy transport bit for bit."""
     cfg = dict(cfg, dt=DT, eps=EPS)
     work = tempfile.mkdtemp(prefix="nbody_ranks_")
-    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, FAKE_RCCL_SLOT_MB="32", NBODY_RCCL_ALLOW_SHARED_DEVICE="1")
+    env = dict(os.environ, NBODY_AMD_LIBRARY=fake_library, FAKE_RCCL_SLOT_MB="32")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_multi_rank_worker.py"), "all_local", str(world),
                           json.dumps(cfg), work], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
@@ -216,3 +219,59 @@ def test_cpp_host_one_process_per_gpu(fake_library, tmp_path, world, flags):
     assert (tmp_path / "ranks.nbs").read_bytes() == (tmp_path / "one.nbs").read_bytes()
     energies = lambda text: [ln.split("E =")[1].split()[0] for ln in text.splitlines() if ln.startswith("step ")]  # noqa: E731
     assert energies(outs[0]) == energies(one.stdout)
+
+
+def test_real_rccl_follows_the_non_blocking_protocol_the_library_uses():
+    """tests/rccl_probe against the REAL librccl with the one rank this box has: ncclCommInitRankConfig(blocking = 0), the poll
+    of ncclCommGetAsyncError, a group of all-gather + send / recv settled before an event is recorded behind it; and a world
+    of two with the peer absent: the creation stays ncclInProgress (it does not block the caller) and ncclCommAbort ends it."""
+    import build_fake_rccl as fake_build
+    exe = fake_build.build_probe()
+    one = subprocess.run([exe, "one"], capture_output=True, text=True, timeout=300)
+    print(one.stdout.strip())
+    assert one.returncode == 0 and "0 wrong words" in one.stdout, one.stdout + one.stderr
+    absent = subprocess.run([exe, "absent"], capture_output=True, text=True, timeout=300)
+    print(absent.stdout.strip())
+    assert absent.returncode == 0 and "in progress" in absent.stdout.lower(), absent.stdout + absent.stderr
+
+
+_LEAVES_AFTER_THE_RENDEZVOUS = """
+import os, time
+import torch.distributed as dist
+dist.init_process_group("gloo")
+box = [None]
+dist.broadcast_object_list(box, src=0)      # the RCCL id arrives ...
+time.sleep(1.0)
+os._exit(0)                                  # ... and this rank never creates its communicator
+"""
+
+
+@pytest.mark.parametrize("library", ["test double", "real RCCL"])
+def test_bench_reports_a_rank_that_never_creates_its_communicator(fake_library, library):
+    """The first contact: a job whose rank 1 is gone before it creates its communicator.  The communicators are non-blocking,
+    so rank 0's nbody_multi_create_rank polls the creation under --exchange-timeout and comes back with NBODY_ERR_DEVICE, and
+    bench.py prints ONE JSON line with "error" and leaves with a non-zero code -- instead of sitting in RCCL's bootstrap until
+    the driver's limit.  With the test double and with the real librccl (whose bootstrap really waits for the peer)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, NBODY_RENDEZVOUS="gloo", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), FAKE_RCCL_TIMEOUT_S="40")
+    if library == "test double":
+        env["NBODY_AMD_LIBRARY"] = fake_library
+    else:
+        env.pop("NBODY_AMD_LIBRARY", None)
+    peer = subprocess.Popen([sys.executable, "-c", _LEAVES_AFTER_THE_RENDEZVOUS], env=dict(env, RANK="1", LOCAL_RANK="1"),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    import time
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "8192", "--steps", "2",
+                          "--warmup", "1", "--single-device", "--no-extra-legs", "--exchange-timeout", "4"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    took = time.time() - t0
+    peer.communicate(timeout=60)
+    lines = [json.loads(x) for x in res.stdout.splitlines() if x.startswith("{")]
+    assert res.returncode != 0 and len(lines) == 1 and "error" in lines[0], res.stdout[-2000:] + res.stderr[-3000:]
+    assert "creating the RCCL communicators" in lines[0]["error"] and "timed out" in lines[0]["error"], lines[0]["error"]
+    assert took < 120, took                                  # interpreter start + the 4 s timeout, not a hang

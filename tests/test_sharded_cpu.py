@@ -19,7 +19,7 @@ def free_port():
 
 
 def test_shard_geometry_and_ring_schedule():
-    from n_body_problem_amd.sharded import shard_geometry, ring_schedule
+    from sharded_harness import shard_geometry, ring_schedule
     assert shard_geometry(1 << 20, 8, 65536) == (1 << 20, 131072)
     assert shard_geometry(1 << 20, 1, 65536) == (1 << 20, 1 << 20)
     assert shard_geometry(1000, 2, 256) == (1024, 512)
@@ -83,7 +83,7 @@ def test_two_ranks_kdk_reproduce_one_rank(tmp_path, oracle_mod):
 
 
 def test_pair_once_geometry_and_tile_orientation():
-    from n_body_problem_amd.sharded import pair_once_geometry, sym_rows_side
+    from sharded_harness import pair_once_geometry, sym_rows_side
     assert pair_once_geometry(1 << 20, 8, 2048) == (1 << 20, 131072)      # 512 splits, 8 groups of 64
     assert pair_once_geometry(1 << 20, 1, 2048) == (1 << 20, 1 << 20)
     assert pair_once_geometry(1000, 2, 256) == (2048, 1024)               # 4 splits -> 8 groups of 1 (4 of padding)

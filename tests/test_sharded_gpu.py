@@ -32,7 +32,7 @@ def single(nb, n, steps):
 
 def test_world_size_one_is_the_single_gpu_system():
     import n_body_problem_amd as nb
-    from n_body_problem_amd.sharded import ShardedNBodySystem
+    from sharded_harness import ShardedNBodySystem
     n, steps = 20000, 3           # not a multiple of the split length: exercises the zero-mass padding
     p, v, e = single(nb, n, steps)
     pos, vel = nb.plummer(n, seed=4321)
@@ -87,7 +87,7 @@ def test_pair_once_ranks_on_one_gpu_reproduce_one_context_bit_for_bit(tmp_path, 
     with the bits of one context on the same padded body set, and that state is the oracle's to rounding."""
     import torch.multiprocessing as mp
     import n_body_problem_amd as nb
-    from n_body_problem_amd.sharded import ShardedNBodySystem
+    from sharded_harness import ShardedNBodySystem
     n, steps, split_len = 40000, 3, 512
     pos, vel = nb.plummer(n, seed=4321)
     s = ShardedNBodySystem(n, device=0, force_mode="pair_once", split_len=split_len, integrator=integrator)

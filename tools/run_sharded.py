@@ -38,7 +38,7 @@ def main():
     import torch
     import torch.distributed as dist
     import n_body_problem_amd as nb
-    from n_body_problem_amd.sharded import sharded_system
+    from n_body_problem_amd.multi import sharded_system
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))

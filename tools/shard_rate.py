@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import n_body_problem_amd as nb  # noqa: E402
-from n_body_problem_amd.sharded import pair_once_geometry, shard_geometry  # noqa: E402
+from n_body_problem_amd import multi  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--bodies", type=int, default=1 << 20)
@@ -26,8 +26,7 @@ if args.morton:
     pos, vel = pos[perm].copy(), vel[perm].copy()
 for L in args.split_len:
     L = L or (nb.pair_once_split_len(n) if args.mode == "pair_once" else nb.default_split_len(n))
-    geo = pair_once_geometry if args.mode == "pair_once" else shard_geometry
-    n_padded, chunk = geo(n, args.world, L)
+    n_padded, chunk, _ = multi.geometry(n, args.world, args.mode, L)
     assert n_padded == n
     lo = args.rank * chunk
     s = nb.NBodySystem(n, row_lo=lo, row_count=chunk, split_len=L)

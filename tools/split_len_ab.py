@@ -13,11 +13,12 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-    lens = [int(x) for x in sys.argv[4:]] or [1024, 2048]
+    morton = "--morton" in sys.argv
+    lens = [int(x) for x in sys.argv[4:] if x != "--morton"] or [1024, 2048]
     pos, vel = nb.plummer(n, seed=1)
     systems = []
     for L in lens:
-        s = nb.NBodySystem(n, split_len=L)
+        s = nb.NBodySystem(n, split_len=L, body_order="morton" if morton else "given")
         s.set_force_mode("pair_once")
         s.setParticlesPosition(pos)
         s.setParticlesVelocity(vel)
