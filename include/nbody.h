@@ -55,8 +55,10 @@ const char *nbody_status_string(int status);
  * nbody_create      : all n_total bodies are rows and columns of this context (one GPU).
  * nbody_create_shard: the context integrates rows [row_lo, row_lo+row_count) against all n_total
  *                     columns (one rank of a multi-GPU run).  split_len = columns per partial sum,
- *                     a multiple of 256, 0 = nbody_default_split_len(n_total) (n_total/128 rounded up to
- *                     a multiple of 256, at most 8192); row_lo must be a
+ *                     a multiple of 64 (of 256 in the pair-once mode), 0 = nbody_default_split_len(n_total) (n_total/128
+ *                     rounded up to a multiple of 256, at most 8192; for systems of ~12 000 to 32 767 bodies the
+ *                     length that makes rows x splits a whole number of waves per SIMD, e.g. 320 at the reference's
+ *                     20 225 bodies); row_lo must be a
  *                     multiple of split_len so that shard boundaries never cut a split.
  * The context owns the acceleration partials (the reference's gravity_sum_array), a stream and, on
  * demand, position/velocity buffers.  n_total need not be padded; the reference's roundup(n,256)+1
@@ -332,8 +334,10 @@ int nbody_device_info(nbody_ctx *ctx, int64_t *out4, char *name, int name_len);
  * Process models: nbody_multi_create -- every rank in this process, driven from the calling host thread (RCCL calls of
  * the local ranks fused with ncclGroupStart/End); nbody_multi_create_rank -- one rank per process (the launch model of
  * torchrun / mpirun): rank 0 calls nbody_multi_unique_id and the caller hands the 128 bytes to every rank by any
- * channel it has.  Failure detection: the communicators are non-blocking (ncclCommInitRankConfig, blocking = 0), so their
- * creation -- the bootstrap, where a job with a missing rank hangs first -- and every RCCL call are polled under the timeout;
+ * channel it has.  Failure detection: the communicators are non-blocking (ncclCommInitRankConfig, blocking = 0) and made by a
+ * helper thread the caller waits for under the timeout, so their creation -- the bootstrap, where a job with a missing rank
+ * hangs first -- is bounded whether or not the RCCL at hand honours blocking = 0 there; RCCL calls that answer ncclInProgress
+ * are polled under the timeout;
  * RCCL's asynchronous error state is polled after every step and inside every wait; nbody_multi_step_n keeps the host at most
  * four steps ahead of the device, so no wait covers more than four steps; a wait longer than the timeout (default 600 s; the
  * environment variable NBODY_EXCHANGE_TIMEOUT_S -- the only one the library reads --, nbody_multi_config.create_timeout_s or

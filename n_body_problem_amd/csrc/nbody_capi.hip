@@ -171,6 +171,22 @@ int64_t nbody_default_split_len(int64_t n_total)
     // the price of 16 B x n_splits per row of partial sums (2 GiB at N = 2^20, ~0.4 % of the step time).
     if (n_total <= 0)
         return kTile;
+    // Small systems (one-wave workgroups of 256 rows x one split, section "small systems" of DESIGN.md): the pass takes
+    // ceil(waves / 1024) rounds on the chip's 1024 SIMDs, so 256-column splits leave the reference's own size -- 20 225 bodies:
+    // 80 x 80 = 6400 waves, 6.25 per SIMD -- waiting for the SIMDs that got seven (profiles/r03_pmc_small_n_one_sided.txt: 83 % of
+    // the large kernel's VALU share).  Where that decomposition needs three rounds or more the split length (a multiple of 64)
+    // is the one (a multiple of 64 between 128 and 512) that minimises rounds x length, rounds = ceil(rows-of-256 x splits /
+    // 1024): 20 225 and 20 000 bodies get 64 splits of 320 columns -- 5120 waves, five per SIMD, 5 x 320 = 1600 columns per
+    // SIMD instead of 7 x 256 = 1792.  256 stays wherever nothing is strictly better.  Still a function of n_total only.
+    const int64_t rb = (n_total + kTile - 1) / kTile;
+    if (n_total < NBODY_PAIR_ONCE_MIN_BODIES && rb * rb > 2048) {
+        auto cost = [&](int64_t L) { return ((n_total + L - 1) / L * rb + 1023) / 1024 * L; };
+        int64_t best = kTile;
+        for (int64_t L = 128; L <= 512; L += 64)
+            if (cost(L) < cost(best))
+                best = L;
+        return best;
+    }
     int64_t len = (n_total + 127) / 128;
     len = (len + kTile - 1) / kTile * kTile;
     return len > 8192 ? 8192 : len;
@@ -358,8 +374,8 @@ int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row
         return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: rows [row_lo,row_lo+row_count) not inside [0,n_total)");
     if (split_len == 0)
         split_len = nbody_default_split_len(n_total);
-    if (split_len < 0 || split_len % kTile != 0)
-        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: split_len must be a positive multiple of 256");
+    if (split_len < 0 || split_len % 64 != 0)
+        return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: split_len must be a positive multiple of 64 (of 256 in the pair-once mode)");
     if (row_lo % split_len != 0)
         return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: row_lo must be a multiple of split_len");
 
@@ -721,9 +737,9 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         }
     }
     if (mode == NBODY_FORCE_SYMMETRIC && c->force_mode != NBODY_FORCE_SYMMETRIC) {
-        if (c->split_len < 256 || c->split_len > 4096)
+        if (c->split_len < 256 || c->split_len > 4096 || c->split_len % kTile != 0)
             return fail(c, NBODY_ERR_INVALID,
-                        "nbody_set_force_mode: the pair-once mode needs 256 <= split_len <= 4096 (create the context with "
+                        "nbody_set_force_mode: the pair-once mode needs 256 <= split_len <= 4096, a multiple of 256 (create the context with "
                         "split_len = nbody_pair_once_split_len(n_total))");
         // the canonical summation: kSymGroups groups of ceil(n_splits / kSymGroups) splits; a context owns whole groups
         const int gs = std::max(1, (c->n_splits + kSymGroups - 1) / kSymGroups);
@@ -1302,8 +1318,9 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         return NBODY_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const int rpl = pick_rows_per_lane(c, a.split_count);
-    // the one-wave kernel forms the equal-mass flag of a one-tile split from the tile it holds: no launch in front
-    a.own_split_mass = rpl == 41 && a.split_len == kTile && c->equal_mass_path;
+    // the one-wave kernel forms the equal-mass flag of a split of one or two tiles itself (from the tile it holds and, for the
+    // second, the masses in memory): no launch in front
+    a.own_split_mass = rpl == 41 && a.split_len <= 2 * kTile && c->equal_mass_path;
     if (!a.own_split_mass) {  // once per step, see the pair-once branch
         if (!c->flags_valid) {
             HIP_TRY(c, launch_split_mass(a.pos, c->split_mass, a.n_total, a.split_len, c->equal_mass_path, c->stream));

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
         const float4 *cur = tile[t & 1];
         const float *ecur = etile[PPS ? (t & 1) : 0];
         float4 pj = cur[0];  // wave-uniform address: broadcast ds_read_b128
+        const int ncols = ((min(kTile, j1 - j0 - t * kTile) + 3) >> 2) << 2;  // a partial last tile: see force_kernel_r4
 #pragma unroll 4
-        for (int jj = 0; jj < kTile; ++jj) {
+        for (int jj = 0; jj < ncols; ++jj) {
             float dx[RPL], dy[RPL], dz[RPL], w[RPL];
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {  // phase 1: separations and r^2 + eps^2, one chain per row
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kTile) void force_kernel(ForceArgs a)
 #define NB_TILE_LOOP(GRD, POST)                                                                                        \
     NB_R4_PRIO_PRE                                                                                               \
     "ds_read_b128 v[0:3], v52\n\t"                                                                               \
-    "s_mov_b32 %[cnt], 64\n"                                                                                     \
+    "s_mov_b32 %[cnt], %[n4]\n"                                                                                     \
     "1:\n\t"                                                                                                     \
     NB_COLUMN("v0", "v1", "v2", "v3", "ds_read_b128 v[4:7], v52 offset:16\n\t", GRD, POST)                             \
     NB_COLUMN("v4", "v5", "v6", "v7", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD, POST)                             \
@@ -294,12 +295,15 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
                 stage = a.pos[jn];
         }
         register unsigned lds asm("v52") = (unsigned)(size_t)(&tile[(t & 1) * kTile]);  // LDS byte address of the tile
+        // four-column iterations of this tile: all 64 but for the last tile of a split whose length is no multiple of the
+        // 256-body tile (split lengths are multiples of 64; a ragged last split's padding columns are zero-mass bodies)
+        const unsigned n4 = (unsigned)__builtin_amdgcn_readfirstlane((min(kTile, j1 - j0 - t * kTile) + 3) >> 2);
         unsigned cnt;
 #define NB_OPERANDS                                                                                                   \
         : "+v"(ax0), "+v"(ay0), "+v"(az0), "+v"(ax1), "+v"(ay1), "+v"(az1), "+v"(ax2), "+v"(ay2), "+v"(az2), "+v"(ax3),    \
           "+v"(ay3), "+v"(az3), "+v"(lds), [cnt] "=&s"(cnt)                                                             \
         : "v"(x0), "v"(y0), "v"(z0), "v"(x1), "v"(y1), "v"(z1), "v"(x2), "v"(y2), "v"(z2), "v"(x3), "v"(y3), "v"(z3),      \
-          "v"(eps2), "v"(tiny), "v"(pinf)                                                                               \
+          "v"(eps2), "v"(tiny), "v"(pinf), [n4] "s"(n4)                                                                 \
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42",   \
           "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "scc", "vcc", "memory"
         if (GUARD)
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
 #define PK_TILE_LOOP(GRD, POST)                                                                                        \
     NB_R4_PRIO_PRE                                                                                               \
     "ds_read_b128 v[0:3], v52\n\t"                                                                               \
-    "s_mov_b32 %[cnt], 64\n"                                                                                     \
+    "s_mov_b32 %[cnt], %[n4]\n"                                                                                     \
     "1:\n\t"                                                                                                     \
     PK_COLUMN("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:16\n\t", GRD, POST)                                 \
     PK_COLUMN("v[4:5]", "v[6:7]", "ds_read_b128 v[0:3], v52 offset:32\n\t", GRD, POST)                                 \
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
     NB_R4_PRIO_PRE                                                                                               \
     "ds_read_b128 v[0:3], v52\n\t"                                                                               \
     "ds_read2_b32 v[56:57], v66 offset1:1\n\t"                                                                   \
-    "s_mov_b32 %[cnt], 64\n"                                                                                     \
+    "s_mov_b32 %[cnt], %[n4]\n"                                                                                     \
     "1:\n\t"                                                                                                     \
     PK_COLUMN_E("v[0:1]", "v[2:3]", "ds_read_b128 v[4:7], v52 offset:16\n\tds_read2_b32 v[64:65], v66 offset0:2 offset1:3\n\t", \
                 GRD, POST, "v[56:57]", PK_ELO)                                                                   \
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4(ForceArgs a)
         : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),      \
           "+{v[48:49]}"(az23), "+{v52}"(lds), "+{v66}"(elds), [cnt] "=&s"(cnt)                                        \
         : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23),              \
-          "{v[16:17]}"(z23), "{v[58:59]}"(er01), "{v[62:63]}"(er23), "{v10}"(tiny), "{v11}"(pinf)                    \
+          "{v[16:17]}"(z23), "{v[58:59]}"(er01), "{v[62:63]}"(er23), "{v10}"(tiny), "{v11}"(pinf), [n4] "s"(n4)      \
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35",     \
           "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v56", "v57", "v64", "v65", "scc",    \
           "vcc", "memory"
@@ -508,6 +512,9 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
             }
         }
         unsigned lds = (unsigned)(size_t)(&tile[(t & 1) * kTile]);
+        // four-column iterations of this tile: all 64 but for the last tile of a split whose length is no multiple of the
+        // 256-body tile (split lengths are multiples of 64; a ragged last split's padding columns are zero-mass bodies)
+        const unsigned n4 = (unsigned)__builtin_amdgcn_readfirstlane((min(kTile, j1 - j0 - t * kTile) + 3) >> 2);
         unsigned cnt;
         if constexpr (PPS) {
             unsigned elds = (unsigned)(size_t)(&etile[(t & 1) * kTile]);
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
         : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),          \
           "+{v[48:49]}"(az23), "+{v52}"(lds), [cnt] "=&s"(cnt)                                                            \
         : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23), "{v[16:17]}"(z23),  \
-          "{v[8:9]}"(epsv), "{v10}"(tiny), "{v11}"(pinf)                                                                  \
+          "{v[8:9]}"(epsv), "{v10}"(tiny), "{v11}"(pinf), [n4] "s"(n4)                                                                  \
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35", "v38",   \
           "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "vcc", "memory"
         if (GUARD)
@@ -558,15 +565,20 @@ __global__ __launch_bounds__(kTile) void force_kernel_r4pk(ForceArgs a)
 // against the 4.8e12 this loop reaches on large systems.  Here a workgroup is one wave: 256 rows x one split, 80 x 79 = 6320
 // waves, six to a SIMD, dealt as slots free up; the wave stages its own 256-column tiles (four float4 a lane, no barrier
 // partner) and runs the identical hand-allocated loop, so each row's sum is the same FMA chain: not a bit changes.
-// Splits of exactly one tile (split_len = 256, every system below 32 768 bodies) need no split_mass_kernel launch in front:
-// the wave holds the split's 256 masses in registers and forms the same flag itself (one launch less per step).
-// ONE_TILE: every split is one 256-column tile (split_len = 256): no second LDS buffer, no columns in flight under the
-// loop -- 16 VGPRs and 4 KiB of LDS less, so that the six or seven waves a SIMD gets at N = 20 225 are all resident at once.
-template <bool GUARD, bool ONE_TILE, bool PPS = false>
+// Splits of up to 512 columns (every system below 32 768 bodies) need no split_mass_kernel launch in front: the wave holds
+// the split's masses in registers and forms the same flag itself (one launch less per step).
+template <bool GUARD, int QT, bool PPS = false>
 __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
 {
-    __shared__ float4 tile[(ONE_TILE ? 1 : 2) * kTile + 1];
-    __shared__ float etile[PPS ? (ONE_TILE ? 1 : 2) * kTile + 2 : 1];  // per-particle softening: eps_j^2 of the columns
+    // QT != 0: the WHOLE split -- at most 64 QT columns, QT = 4 ... 8 -- is staged at once: no second buffer, no columns in
+    // flight under the loop.  4 KiB of LDS for 256-column splits, 5 KiB for the 320-column splits of the reference's own size:
+    // with the double-buffered 8 KiB only 19 of the 20 one-wave workgroups a CU gets there were resident (4.75 waves per SIMD:
+    // a sixth round, measured 118 us per pass against 110 with 256-column splits).  QT = 0: longer splits, two 256-column
+    // buffers used in turn.
+    constexpr bool WHOLE = QT != 0;
+    constexpr int kStageCols = WHOLE ? 64 * QT : 2 * kTile, NS = WHOLE ? QT : 4;
+    __shared__ float4 tile[kStageCols + 1];
+    __shared__ float etile[PPS ? kStageCols + 2 : 1];  // per-particle softening: eps_j^2 of the columns
 
     const int lane = threadIdx.x;
     int split = a.split_first + blockIdx.y;
@@ -574,7 +586,7 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
         split += a.skip_count;
     const int j0 = split * a.split_len;
     const int j1 = min(j0 + a.split_len, a.n_total);
-    const int ntiles = ONE_TILE ? 1 : (j1 - j0 + kTile - 1) / kTile;
+    const int ntiles = (j1 - j0 + kTile - 1) / kTile;
     const int row_base = blockIdx.x * kTile + 4 * (lane & 15) + (lane >> 4);  // rows row_base + 64 k: see force_kernel_r4pk
 
     float4 p[4];
@@ -598,10 +610,10 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
     const nb_f2 epsv = {a.eps2, 0.f};
     const float tiny = kGuardMin, pinf = __builtin_inff();
 
-    float4 stage[4];  // four columns of the tile per lane; an out-of-range column is a zero-mass body at the origin
-    float stage_e[4];
+    float4 stage[NS];  // NS columns per lane (the split, or its first tile); an out-of-range column is a zero-mass body at the origin
+    float stage_e[NS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NS; ++k) {
         const int c = j0 + k * 64 + lane;
         stage[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         stage_e[k] = 0.f;
@@ -619,8 +631,13 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
             const unsigned m0 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, stage[0].w));
             bool differs = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < NS; ++k)
                 differs |= __builtin_bit_cast(unsigned, stage[k].w) != m0;
+            if (!WHOLE)  // the columns beyond the first tile: their masses straight from memory
+                for (int c = kTile + lane; c < a.split_len; c += 64) {
+                    const float m = j0 + c < a.n_total ? a.pos[j0 + c].w : 0.f;  // a ragged split's missing bodies: mass 0
+                    differs |= __builtin_bit_cast(unsigned, m) != m0;
+                }
             const float mf = __builtin_bit_cast(float, m0);
             if (!__builtin_amdgcn_ballot_w64(differs) && fabsf(mf) <= 3.4e38f)
                 split_mass = mf;
@@ -631,19 +648,19 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
     const bool uniform = split_mass == split_mass;
 
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NS; ++k) {
         tile[k * 64 + lane] = stage[k];
         if (PPS)
             etile[k * 64 + lane] = stage_e[k] * stage_e[k];
     }
     if (lane == 0)
-        tile[(ONE_TILE ? 1 : 2) * kTile] = make_float4(0.f, 0.f, 0.f, 0.f);
+        tile[kStageCols] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PPS && lane < 2)
-        etile[(ONE_TILE ? 1 : 2) * kTile + lane] = 0.f;
+        etile[kStageCols + lane] = 0.f;
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        if (!ONE_TILE && t + 1 < ntiles) {  // in flight under the tile's arithmetic
+        if (!WHOLE && t + 1 < ntiles) {  // in flight under the tile's arithmetic
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = j0 + (t + 1) * kTile + k * 64 + lane;
@@ -656,24 +673,27 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
                 }
             }
         }
-        unsigned lds = (unsigned)(size_t)(&tile[ONE_TILE ? 0 : (t & 1) * kTile]);
+        unsigned lds = (unsigned)(size_t)(&tile[WHOLE ? t * kTile : (t & 1) * kTile]);
+        // four-column iterations of this tile: all 64 but for the last tile of a split whose length is no multiple of the
+        // 256-body tile (split lengths are multiples of 64; a ragged last split's padding columns are zero-mass bodies)
+        const unsigned n4 = (unsigned)__builtin_amdgcn_readfirstlane((min(kTile, j1 - j0 - t * kTile) + 3) >> 2);
         unsigned cnt;
         if constexpr (PPS) {
-            unsigned elds = (unsigned)(size_t)(&etile[ONE_TILE ? 0 : (t & 1) * kTile]);
+            unsigned elds = (unsigned)(size_t)(&etile[WHOLE ? t * kTile : (t & 1) * kTile]);
             if (GUARD)
                 asm volatile(PK_TILE_LOOP_E(PK_GUARD, PK_POST) PK_OPERANDS_E);
             else if (uniform)
                 asm volatile(PK_TILE_LOOP_E(PK_NOGUARD, PK_POSTU) PK_OPERANDS_E);
             else
                 asm volatile(PK_TILE_LOOP_E(PK_NOGUARD, PK_POST) PK_OPERANDS_E);
-            if (!ONE_TILE && t + 1 < ntiles) {
+            if (!WHOLE && t + 1 < ntiles) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     tile[((t + 1) & 1) * kTile + k * 64 + lane] = stage[k];
                     etile[((t + 1) & 1) * kTile + k * 64 + lane] = stage_e[k] * stage_e[k];
                 }
             }
-            if (!ONE_TILE)
+            if (!WHOLE)
                 __syncthreads();
             continue;
         }
@@ -681,7 +701,7 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
         : "+{v[28:29]}"(ax01), "+{v[32:33]}"(ay01), "+{v[36:37]}"(az01), "+{v[40:41]}"(ax23), "+{v[44:45]}"(ay23),          \
           "+{v[48:49]}"(az23), "+{v52}"(lds), [cnt] "=&s"(cnt)                                                            \
         : "{v[14:15]}"(x01), "{v[18:19]}"(y01), "{v[12:13]}"(z01), "{v[22:23]}"(x23), "{v[26:27]}"(y23), "{v[16:17]}"(z23),  \
-          "{v[8:9]}"(epsv), "{v10}"(tiny), "{v11}"(pinf)                                                                  \
+          "{v[8:9]}"(epsv), "{v10}"(tiny), "{v11}"(pinf), [n4] "s"(n4)                                                                  \
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v20", "v21", "v24", "v25", "v30", "v31", "v34", "v35", "v38",   \
           "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "vcc", "memory"
         if (GUARD)
@@ -691,12 +711,12 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
         else
             asm volatile(PK_TILE_LOOP(PK_NOGUARD, PK_POST) PK_OPERANDS);
 #undef PK_OPERANDS
-        if (!ONE_TILE && t + 1 < ntiles) {
+        if (!WHOLE && t + 1 < ntiles) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 tile[((t + 1) & 1) * kTile + k * 64 + lane] = stage[k];
         }
-        if (!ONE_TILE)
+        if (!WHOLE)
             __syncthreads();
     }
 
@@ -708,31 +728,31 @@ __global__ __launch_bounds__(64) void force_kernel_r4pk_w1(ForceArgs a)
     if (row_base + 192 < a.row_count) out[row_base + 192] = make_float4(ax23.y * sc, ay23.y * sc, az23.y * sc, 0.f);
 }
 
+template <int QT>
+static void launch_w1(const ForceArgs &a, dim3 grid, hipStream_t stream)
+{
+    if (a.eps_pp) {  // per-particle softening (a particle may have eps = 0: the guard stays on when eps = 0)
+        if (a.eps2 > 0.f)
+            hipLaunchKernelGGL((force_kernel_r4pk_w1<false, QT, true>), grid, dim3(64), 0, stream, a);
+        else
+            hipLaunchKernelGGL((force_kernel_r4pk_w1<true, QT, true>), grid, dim3(64), 0, stream, a);
+    } else if (a.eps2 > 0.f) {
+        hipLaunchKernelGGL((force_kernel_r4pk_w1<false, QT>), grid, dim3(64), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((force_kernel_r4pk_w1<true, QT>), grid, dim3(64), 0, stream, a);
+    }
+}
+
 static hipError_t launch_forces_r4pk_w1(const ForceArgs &a, hipStream_t stream)
 {
     dim3 grid((a.row_count + kTile - 1) / kTile, a.split_count, 1);
-    if (a.eps_pp) {  // per-particle softening (a particle may have eps = 0: the guard stays on when eps = 0)
-        if (a.split_len == kTile) {
-            if (a.eps2 > 0.f)
-                hipLaunchKernelGGL((force_kernel_r4pk_w1<false, true, true>), grid, dim3(64), 0, stream, a);
-            else
-                hipLaunchKernelGGL((force_kernel_r4pk_w1<true, true, true>), grid, dim3(64), 0, stream, a);
-        } else if (a.eps2 > 0.f) {
-            hipLaunchKernelGGL((force_kernel_r4pk_w1<false, false, true>), grid, dim3(64), 0, stream, a);
-        } else {
-            hipLaunchKernelGGL((force_kernel_r4pk_w1<true, false, true>), grid, dim3(64), 0, stream, a);
-        }
-        return hipGetLastError();
-    }
-    if (a.split_len == kTile) {
-        if (a.eps2 > 0.f)
-            hipLaunchKernelGGL((force_kernel_r4pk_w1<false, true>), grid, dim3(64), 0, stream, a);
-        else
-            hipLaunchKernelGGL((force_kernel_r4pk_w1<true, true>), grid, dim3(64), 0, stream, a);
-    } else if (a.eps2 > 0.f) {
-        hipLaunchKernelGGL((force_kernel_r4pk_w1<false, false>), grid, dim3(64), 0, stream, a);
-    } else {
-        hipLaunchKernelGGL((force_kernel_r4pk_w1<true, false>), grid, dim3(64), 0, stream, a);
+    switch (a.split_len <= 2 * kTile ? (a.split_len + 63) / 64 : 0) {  // splits of up to 512 columns are staged whole
+    case 0: launch_w1<0>(a, grid, stream); break;
+    case 5: launch_w1<5>(a, grid, stream); break;
+    case 6: launch_w1<6>(a, grid, stream); break;
+    case 7: launch_w1<7>(a, grid, stream); break;
+    case 8: launch_w1<8>(a, grid, stream); break;
+    default: launch_w1<4>(a, grid, stream); break;  // 256 columns or fewer
     }
     return hipGetLastError();
 }

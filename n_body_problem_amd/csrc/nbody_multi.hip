@@ -19,10 +19,10 @@
 // NBODY_TRANSPORT_PEER_COPY (single process only) moves the same slices with hipMemcpyPeerAsync instead of RCCL: RCCL
 // refuses two ranks on one device, so this is also how two shards on ONE GPU are tested against a single context.
 //
-// Failure detection: the communicators are NON-BLOCKING (ncclCommInitRankConfig, blocking = 0): creation and
-// every RCCL call return at once and the library polls ncclCommGetAsyncError under its timeout -- so a peer that never
-// arrives is reported by nbody_multi_create* itself (the bootstrap is the first thing that can hang), and nothing is recorded
-// on a stream behind an RCCL call before RCCL says the call has been enqueued.  The asynchronous error state is polled after
+// Failure detection: the communicators are made NON-BLOCKING (ncclCommInitRankConfig, blocking = 0) by a helper
+// thread the caller waits for under its timeout -- so a peer that never arrives is reported by nbody_multi_create* itself (the
+// bootstrap is the first thing that can hang; RCCL 2.27.7 sits in it inside the call) -- and after every RCCL call that answers
+// ncclInProgress the library polls ncclCommGetAsyncError before it records anything on the stream behind the call.  The asynchronous error state is polled after
 // every step and inside every wait; a wait that exceeds the timeout aborts the communicators and returns NBODY_ERR_DEVICE
 // instead of hanging on a dead peer.
 //
@@ -37,7 +37,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -201,7 +203,7 @@ extern "C" int nbody_multi_geometry(int64_t n_bodies, int world_size, int force_
         return NBODY_ERR_INVALID;
     if (split_len == 0)
         split_len = force_mode == NBODY_FORCE_SYMMETRIC ? nbody_pair_once_split_len(n_bodies) : nbody_default_split_len(n_bodies);
-    if (split_len <= 0 || split_len % 256 != 0)
+    if (split_len <= 0 || split_len % 64 != 0 || (force_mode == NBODY_FORCE_SYMMETRIC && split_len % 256 != 0))
         return NBODY_ERR_INVALID;
     const int64_t n_splits = n_bodies > 0 ? (n_bodies + split_len - 1) / split_len : 1;
     int64_t padded, chunk;
@@ -344,7 +346,7 @@ static int create_common(nbody_multi **out, const nbody_multi_config *cfg, int w
     int64_t padded = 0, chunk = 0, split = 0;
     if (nbody_multi_geometry(cfg->n_bodies, world, force_mode, cfg->split_len, &padded, &chunk, &split) != NBODY_OK)
         return mfail(nullptr, NBODY_ERR_INVALID,
-                     "nbody_multi_create: bad geometry (n_bodies >= 0, split_len a multiple of 256, and the pair-once mode "
+                     "nbody_multi_create: bad geometry (n_bodies >= 0, split_len a multiple of 64 -- of 256 in the pair-once mode --, and the pair-once mode "
                      "shards over 1, 2, 4 or 8 ranks)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -408,54 +410,115 @@ static int nccl_settle(nbody_multi *m, const char *what)
 
 // One non-blocking communicator per local rank from the id (one process per GPU: one rank; every rank in this process: all of
 // them inside one group, what ncclCommInitAll does with blocking ones).  The bootstrap is where a job with a missing rank
-// hangs first: the wait for it is bounded like every other.
-static int init_communicators(nbody_multi *m, const ncclUniqueId &id)
+// hangs first, and RCCL 2.27.7 (ROCm 7.2) sits in it INSIDE ncclCommInitRankConfig whatever config.blocking says
+// (tests/rccl_probe, profiles/r04_rccl_nonblocking_probe.txt) -- so the creation runs in a helper thread and the caller waits
+// for it under the timeout: where RCCL honours blocking = 0 the thread polls ncclCommGetAsyncError, where it does not the
+// thread sits in the call; either way nbody_multi_create* is back in time.  A helper that is still inside RCCL then is left
+// behind (it owns everything it touches; if it ever comes back it aborts what it made).
+struct CommCreation {
+    std::vector<int> devices, ranks;
+    int world = 0;
+    ncclUniqueId id;
+    std::vector<ncclComm_t> comms;
+    ncclResult_t result = ncclSuccess;
+    std::string where;
+    std::atomic<bool> done{false}, abandoned{false};
+};
+
+static void create_communicators_thread(std::shared_ptr<CommCreation> job)
 {
     ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
     config.blocking = 0;
-    const bool group = m->ranks.size() > 1;
-    if (group) {
-        ncclResult_t g = ncclGroupStart();
-        if (g != ncclSuccess)
-            return mfail(m, NBODY_ERR_DEVICE, std::string("ncclGroupStart: RCCL: ") + ncclGetErrorString(g));
-    }
+    const bool group = job->devices.size() > 1;
     ncclResult_t bad = ncclSuccess;
-    for (Rank &r : m->ranks) {
-        if (hipSetDevice(r.device) != hipSuccess) {
+    const char *where = "ncclCommInitRankConfig";
+    if (group) {
+        bad = ncclGroupStart();
+        where = "ncclGroupStart";
+    }
+    for (size_t i = 0; i < job->devices.size() && bad == ncclSuccess; ++i) {
+        if (hipSetDevice(job->devices[i]) != hipSuccess) {
             bad = ncclUnhandledCudaError;
+            where = "hipSetDevice";
             break;
         }
-        const ncclResult_t q = ncclCommInitRankConfig(&r.nccl, m->world, id, r.rank, &config);
+        const ncclResult_t q = ncclCommInitRankConfig(&job->comms[i], job->world, job->id, job->ranks[i], &config);
         if (q != ncclSuccess && q != ncclInProgress) {
             bad = q;
-            r.nccl = nullptr;
-            break;
+            where = "ncclCommInitRankConfig";
+            job->comms[i] = nullptr;
         }
     }
     if (group) {
         const ncclResult_t g = ncclGroupEnd();
-        if (bad == ncclSuccess && g != ncclSuccess && g != ncclInProgress)
+        if (bad == ncclSuccess && g != ncclSuccess && g != ncclInProgress) {
             bad = g;
+            where = "ncclGroupEnd";
+        }
     }
-    if (bad != ncclSuccess) {
-        bool dup = false;
-        for (size_t i = 0; i < m->ranks.size(); ++i)
-            for (size_t j = 0; j < i; ++j)
-                dup |= m->ranks[i].device == m->ranks[j].device;
-        abort_communicators(m);
-        return mfail(m, NBODY_ERR_DEVICE, std::string("ncclCommInitRankConfig: RCCL: ") + ncclGetErrorString(bad) +
-                                              (dup ? " (two ranks on one device: NBODY_TRANSPORT_PEER_COPY serves those)" : ""));
+    // a communicator that honours blocking = 0 is ready once its asynchronous state has left ncclInProgress
+    for (size_t i = 0; i < job->comms.size() && bad == ncclSuccess; ++i)
+        while (job->comms[i] && !job->abandoned.load()) {
+            ncclResult_t state = ncclSuccess;
+            const ncclResult_t q = ncclCommGetAsyncError(job->comms[i], &state);
+            if (q != ncclSuccess || (state != ncclSuccess && state != ncclInProgress)) {
+                bad = q != ncclSuccess ? q : state;
+                where = "creating the RCCL communicators";
+                break;
+            }
+            if (state == ncclSuccess)
+                break;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    if (bad != ncclSuccess || job->abandoned.load()) {  // nobody will use them
+        for (ncclComm_t &c : job->comms)
+            if (c) {
+                (void)ncclCommAbort(c);
+                c = nullptr;
+            }
     }
-    int rc = nccl_settle(m, "creating the RCCL communicators");
-    if (rc != NBODY_OK) {
-        bool dup = false;
-        for (size_t i = 0; i < m->ranks.size(); ++i)
-            for (size_t j = 0; j < i; ++j)
-                dup |= m->ranks[i].device == m->ranks[j].device;
-        if (dup)
-            m->err += " (two ranks on one device: NBODY_TRANSPORT_PEER_COPY serves those)";
+    job->result = bad;
+    job->where = where;
+    job->done.store(true);
+}
+
+static int init_communicators(nbody_multi *m, const ncclUniqueId &id)
+{
+    std::shared_ptr<CommCreation> job;
+    try {
+        job = std::make_shared<CommCreation>();
+        for (const Rank &r : m->ranks) {
+            job->devices.push_back(r.device);
+            job->ranks.push_back(r.rank);
+        }
+        job->comms.assign(m->ranks.size(), nullptr);
+        job->world = m->world;
+        job->id = id;
+        std::thread(create_communicators_thread, job).detach();
+    } catch (...) {
+        return mfail(m, NBODY_ERR_ALLOC, "creating the RCCL communicators: no helper thread");
     }
-    return rc;
+    bool dup = false;
+    for (size_t i = 0; i < m->ranks.size(); ++i)
+        for (size_t j = 0; j < i; ++j)
+            dup |= m->ranks[i].device == m->ranks[j].device;
+    const char *hint = dup ? " (two ranks on one device: NBODY_TRANSPORT_PEER_COPY serves those)" : "";
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!job->done.load()) {
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > m->timeout_s) {
+            job->abandoned.store(true);
+            m->failed = true;
+            return mfail(m, NBODY_ERR_DEVICE, "creating the RCCL communicators: timed out after " + std::to_string((int)waited) +
+                                                  " s (a peer rank never arrived: RCCL is still in its bootstrap)" + hint);
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    if (job->result != ncclSuccess)
+        return mfail(m, NBODY_ERR_DEVICE, job->where + ": RCCL: " + ncclGetErrorString(job->result) + hint);
+    for (size_t i = 0; i < m->ranks.size(); ++i)
+        m->ranks[i].nccl = job->comms[i];
+    return NBODY_OK;
 }
 
 extern "C" int nbody_multi_create(nbody_multi **out, const nbody_multi_config *cfg, const int *devices, int n_devices)

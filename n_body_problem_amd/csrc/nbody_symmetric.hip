@@ -451,6 +451,49 @@ typedef float nb_f2 __attribute__((ext_vector_type(2)));
     "s_setprio 0\n\t"                                                                                            \
     "s_waitcnt lgkmcnt(0)\n"
 
+// ---- EIGHT rows per lane, per-particle softening, EQUAL-MASS tiles (round 4): S8 with S10's first addend -- the masses leave the
+// loop again (the sums collect d * inv^3 and are multiplied by the other side's mass when they are written), 7.5 packed
+// instructions + 1 transcendental per pair instead of 8.5 + 1: what a body set with ONE mass and individual softening lengths
+// gets (the benchmark's sphere with vel.w in use).  Lives in the ROWS8 = 3 instantiation beside S10, chosen per tile.
+#define S12_STEP(NEXT)                                                                                           \
+    "s_waitcnt lgkmcnt(6)\n\t" /* positions and eps_j^2 of the column pair have arrived (the permutes may be in flight) */ \
+    S10_PRE2("v[12:13]", "v[16:17]", "v[14:15]", "v[132:133]")                                                   \
+    S8_RSQ NB_SYM_GAP                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    NB_SYM_PRIO_POST                                                                                             \
+    S8_POST2("v[64:65]", "v[66:67]", "v[68:69]", "v[70:71]", "v[72:73]", "v[74:75]")                             \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S10_PRE2("v[20:21]", "v[24:25]", "v[18:19]", "v[136:137]")                                                   \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S8_POST2("v[76:77]", "v[78:79]", "v[80:81]", "v[82:83]", "v[84:85]", "v[86:87]")                             \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S10_PRE2("v[48:49]", "v[52:53]", "v[22:23]", "v[140:141]")                                                   \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S8_POST2("v[88:89]", "v[90:91]", "v[92:93]", "v[94:95]", "v[96:97]", "v[98:99]")                             \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S10_PRE2("v[56:57]", "v[60:61]", "v[26:27]", "v[144:145]")                                                   \
+    NEXT /* the next step's positions and eps_j^2 */                                                             \
+    S8_RSQ NB_SYM_GAP NB_SYM_PRIO_POST                                                                           \
+    S8_POST2("v[100:101]", "v[102:103]", "v[104:105]", "v[106:107]", "v[108:109]", "v[110:111]")                 \
+    NB_SYM_PRIO_PRE                                                                                              \
+    S8_ROTATE
+#define S12_GROUP_LOOP                                                                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+    S2_READ("0", "32", "128", "160") S10_EPS("0", "32")                                                          \
+    S8_ROTATE /* of zeros: primes the in-order LDS queue */                                                      \
+    NB_SYM_PRIO_PRE                                                                                              \
+    "s_mov_b32 %[cnt], 8\n"                                                                                      \
+    "1:\n\t"                                                                                                     \
+    S12_STEP(S2_READ("1", "33", "129", "161") S10_EPS("1", "33"))                                                \
+    S12_STEP(S2_READ("2", "34", "130", "162") S10_EPS("2", "34"))                                                \
+    S12_STEP(S2_READ("3", "35", "131", "163") S10_EPS("3", "35"))                                                \
+    S12_STEP(S10_ADVANCE S2_READ("0", "32", "128", "160") S10_EPS("0", "32"))                                    \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                 \
+    "s_cbranch_scc1 1b\n\t"                                                                                      \
+    "s_setprio 0\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"
+
 // ---- the same two-columns-per-step loop for tiles with arbitrary masses: 8 packed instructions + 1 transcendental per pair
 // (one-column loop: 16 + 1).  The group's masses are staged as a fourth array m[128] behind x, y, z and read at the END of
 // a step (the positions are consumed by the PRE blocks, the masses by the POST blocks of both batches).
@@ -626,7 +669,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
     const float mass_rows = GUARD ? __builtin_nanf("") : a.split_mass[t.x], mass_cols = GUARD ? mass_rows : a.split_mass[t.y];
     // ... and only when every pass is full: the lanes of a partial last pass (split lengths that are not a multiple of the
     // rows per pass, e.g. 768 with two waves) carry dummy rows whose zero MASS is what keeps them out of the column sums
-    const bool uniform = ROWS8 < 3 && !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;  // 3: masses in the loop
+    const bool uniform = ROWS8 <= 3 && !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;  // 4: masses in the loop
     const float row_scale = uniform ? mass_cols : 1.f, col_scale = uniform ? mass_rows : 1.f;
 
     for (int c = tid; c < L; c += kSymThreads)
@@ -831,8 +874,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
     };
     // eight rows per lane (S8_GROUP_LOOP: equal-mass tiles; S9_GROUP_LOOP: arbitrary masses): a wave owns 512 rows of a pass
     auto passes8 = [&](auto general_tag) {
-        constexpr int VARIANT8 = decltype(general_tag)::value;  // 0: equal-mass tile (S8), 1: arbitrary masses (S9), 2: + per-particle softening (S10)
-        constexpr bool GENERAL = VARIANT8 >= 1, PPS8 = VARIANT8 == 2;
+        // 0: equal-mass tile (S8), 1: arbitrary masses (S9), 2: arbitrary masses + per-particle softening (S10), 3: equal-mass tile +
+        // per-particle softening (S12)
+        constexpr int VARIANT8 = decltype(general_tag)::value;
+        constexpr bool GENERAL = VARIANT8 == 1 || VARIANT8 == 2, PPS8 = VARIANT8 >= 2;
         float *estage8 = lds.sz + L + wave * 128;  // PPS8: the group's eps_j^2, the 64 columns twice
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         // Which of the 64 bodies of a row block / column group a lane holds: 4 (lane mod 16) + lane / 16, so that the four
@@ -895,7 +940,18 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
                 unsigned addr = (unsigned)(size_t)lds.stage + 4u * (unsigned)lane, addr_z = addr + 1024u, cnt;
                 const unsigned next_lane = 4u * ((lane + 1) & 63);
                 const nb_f2 epsv = {a.eps2, 0.f};
-                if constexpr (PPS8) {
+                if constexpr (VARIANT8 == 3) {
+                    unsigned addr_e = (unsigned)(size_t)estage8 + 4u * (unsigned)lane;
+                    asm volatile(S12_GROUP_LOOP
+                                 : "+{v[64:79]}"(ra0), "+{v[80:95]}"(ra1), "+{v[96:111]}"(ra2), "+{v[36:37]}"(cx), "+{v[40:41]}"(cy),
+                                   "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), "+{v146}"(addr_e), [cnt] "=&s"(cnt)
+                                 : "{v[12:27]}"(rows), "{v[48:49]}"(xy4), "{v[52:53]}"(xy5), "{v[56:57]}"(xy6), "{v[60:61]}"(xy7),
+                                   "{v[8:9]}"(epsv), "{v10}"(next_lane), "{v[132:133]}"(e01), "{v[136:137]}"(e23),
+                                   "{v[140:141]}"(e45), "{v[144:145]}"(e67)
+                                 : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
+                                   "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v58", "v59", "v134", "v135",
+                                   "scc", "memory");
+                } else if constexpr (PPS8) {
                     unsigned addr_e = (unsigned)(size_t)estage8 + 4u * (unsigned)lane;
                     asm volatile(S10_GROUP_LOOP
                                  : "+{v[64:79]}"(ra0), "+{v[80:95]}"(ra1), "+{v[96:111]}"(ra2), "+{v[36:37]}"(cx), "+{v[40:41]}"(cy),
@@ -960,7 +1016,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
     if constexpr (ROWS8 != 0 && !GUARD) {
         if (L % (kSymThreads * 8) == 0) {  // whole passes of 512 rows per wave (dummy rows would need their zero mass: see above)
             if constexpr (ROWS8 == 3) {
-                passes8(std::integral_constant<int, 2>{});
+                if (uniform)
+                    passes8(std::integral_constant<int, 3>{});
+                else
+                    passes8(std::integral_constant<int, 2>{});
                 done = true;
             } else if (uniform) {
                 passes8(std::integral_constant<int, 0>{});

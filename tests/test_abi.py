@@ -43,12 +43,22 @@ def test_abi_version_and_status_strings(lib):
 
 
 def test_default_split_len_is_tile_aligned_and_sharding_independent(lib):
-    for n in (1, 255, 256, 257, 1024, 20000, 65536, 1 << 20, (1 << 22) + 1):
+    for n in (1, 255, 256, 257, 1024, 8192, 65536, 1 << 20, (1 << 22) + 1):
         s = lib.nbody_default_split_len(n)
         assert s % 256 == 0 and s >= 256
         assert s <= 8192 and (n + s - 1) // s <= max(128, (n + 8191) // 8192)
     assert lib.nbody_default_split_len(1 << 20) == 8192 and lib.nbody_default_split_len(1 << 22) == 8192
-    assert lib.nbody_default_split_len(65536) == 512 and lib.nbody_default_split_len(20000) == 256
+    assert lib.nbody_default_split_len(65536) == 512 and lib.nbody_default_split_len(10241) == 256
+    # round 4, small systems (one wave = 256 rows x one split): where 256-column splits need three rounds or more on the
+    # 1024 SIMDs, the split length (a multiple of 64) makes rows x splits a whole number of rounds
+    assert lib.nbody_default_split_len(20225) == 320 and lib.nbody_default_split_len(20000) == 320      # 80 x 64 = 5 x 1024 waves
+    for n in range(11800, 32768, 997):
+        s = lib.nbody_default_split_len(n)
+        waves = -(-n // s) * -(-n // 256)
+        rounds = -(-waves // 1024)
+        assert s % 64 == 0 and 128 <= s <= 512 and waves <= 1024 * rounds
+        rb = -(-n // 256)
+        assert rounds * s <= -(-(rb * rb) // 1024) * 256, (n, s)               # never more columns per SIMD than 256-column splits
 
 
 def test_pair_once_split_len_depends_on_the_body_count_only(lib):

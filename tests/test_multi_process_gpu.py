@@ -224,15 +224,17 @@ def test_cpp_host_one_process_per_gpu(fake_library, tmp_path, world, flags):
 def test_real_rccl_follows_the_non_blocking_protocol_the_library_uses():
     """tests/rccl_probe against the REAL librccl with the one rank this box has: ncclCommInitRankConfig(blocking = 0), the poll
     of ncclCommGetAsyncError, a group of all-gather + send / recv settled before an event is recorded behind it; and a world
-    of two with the peer absent: the creation stays ncclInProgress (it does not block the caller) and ncclCommAbort ends it."""
+    of two with the peer absent, the creation in a helper thread with a limit as the library does it: the caller is back in
+    time whether this RCCL honours blocking = 0 for the creation or sits in its bootstrap inside the call (RCCL 2.27.7 of
+    ROCm 7.2 does the latter -- which is why the library does not rely on the flag)."""
     import build_fake_rccl as fake_build
     exe = fake_build.build_probe()
     one = subprocess.run([exe, "one"], capture_output=True, text=True, timeout=300)
     print(one.stdout.strip())
     assert one.returncode == 0 and "0 wrong words" in one.stdout, one.stdout + one.stderr
-    absent = subprocess.run([exe, "absent"], capture_output=True, text=True, timeout=300)
+    absent = subprocess.run([exe, "absent"], capture_output=True, text=True, timeout=120)
     print(absent.stdout.strip())
-    assert absent.returncode == 0 and "in progress" in absent.stdout.lower(), absent.stdout + absent.stderr
+    assert absent.returncode == 0 and ("has not returned" in absent.stdout or "honoured" in absent.stdout), absent.stdout + absent.stderr
 
 
 _LEAVES_AFTER_THE_RENDEZVOUS = """
