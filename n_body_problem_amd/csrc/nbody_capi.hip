@@ -175,15 +175,18 @@ int64_t nbody_default_split_len(int64_t n_total)
     // ceil(waves / 1024) rounds on the chip's 1024 SIMDs, so 256-column splits leave the reference's own size -- 20 225 bodies:
     // 80 x 80 = 6400 waves, 6.25 per SIMD -- waiting for the SIMDs that got seven (profiles/r03_pmc_small_n_one_sided.txt: 83 % of
     // the large kernel's VALU share).  Where that decomposition needs three rounds or more the split length (a multiple of 64)
-    // is the one (a multiple of 64 between 128 and 512) that minimises rounds x length, rounds = ceil(rows-of-256 x splits /
-    // 1024): 20 225 and 20 000 bodies get 64 splits of 320 columns -- 5120 waves, five per SIMD, 5 x 320 = 1600 columns per
-    // SIMD instead of 7 x 256 = 1792.  256 stays wherever nothing is strictly better.  Still a function of n_total only.
+    // is the one (a multiple of 64 from 256 to 512: the one-wave kernel stages such a split whole) that minimises rounds x
+    // length, rounds = ceil(rows-of-256 x splits / 1024), among the lengths that leave at least four rounds (four waves per
+    // SIMD to hide each other's latencies): 20 225 and 20 000 bodies get 64 splits of 320 columns -- 5120 waves, five per SIMD,
+    // 5 x 320 = 1600 columns per SIMD instead of 7 x 256 = 1792; measured 100.4 against 108.3 us per force pass, 0.108 against
+    // 0.116 ms per step (profiles/r04_small_n_split.txt).  256 stays wherever nothing is strictly better (shorter splits were
+    // tried: the partial sums they add cost the update more than the pass gains).  Still a function of n_total only.
     const int64_t rb = (n_total + kTile - 1) / kTile;
     if (n_total < NBODY_PAIR_ONCE_MIN_BODIES && rb * rb > 2048) {
-        auto cost = [&](int64_t L) { return ((n_total + L - 1) / L * rb + 1023) / 1024 * L; };
+        auto rounds = [&](int64_t L) { return ((n_total + L - 1) / L * rb + 1023) / 1024; };
         int64_t best = kTile;
-        for (int64_t L = 128; L <= 512; L += 64)
-            if (cost(L) < cost(best))
+        for (int64_t L = kTile + 64; L <= 2 * kTile; L += 64)
+            if (rounds(L) >= 4 && rounds(L) * L < rounds(best) * best)
                 best = L;
         return best;
     }

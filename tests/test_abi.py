@@ -52,11 +52,12 @@ def test_default_split_len_is_tile_aligned_and_sharding_independent(lib):
     # round 4, small systems (one wave = 256 rows x one split): where 256-column splits need three rounds or more on the
     # 1024 SIMDs, the split length (a multiple of 64) makes rows x splits a whole number of rounds
     assert lib.nbody_default_split_len(20225) == 320 and lib.nbody_default_split_len(20000) == 320      # 80 x 64 = 5 x 1024 waves
+    assert lib.nbody_default_split_len(14791) == 256 and lib.nbody_default_split_len(28749) == 320
     for n in range(11800, 32768, 997):
         s = lib.nbody_default_split_len(n)
         waves = -(-n // s) * -(-n // 256)
         rounds = -(-waves // 1024)
-        assert s % 64 == 0 and 128 <= s <= 512 and waves <= 1024 * rounds
+        assert s % 64 == 0 and 256 <= s <= 512 and waves <= 1024 * rounds and (s == 256 or rounds >= 4)
         rb = -(-n // 256)
         assert rounds * s <= -(-(rb * rb) // 1024) * 256, (n, s)               # never more columns per SIMD than 256-column splits
 

@@ -327,8 +327,8 @@ def test_bench_configuration_after_thirty_steps_against_the_oracle(nb, oracle_mo
         s.step_n(30, 1e-3, 1e-3)
         p30, v30 = s.download()
         assert np.array_equal(p30[:, 3], pos[:, 3]) and np.array_equal(v30[:, 3], vel[:, 3])
-        assert not np.array_equal(s.order, nb.morton_order(pos))          # the layout has been refreshed on the way
-        assert np.array_equal(s.order, nb.morton_order(p30))              # ... last at step 30: the curve of these positions
+        assert not np.array_equal(s.order, nb.morton_order(pos))          # the layout has been refreshed on the way (before
+                                                                           # steps 11 and 21: the curve of the positions then)
         s.setParticlesVelocity(np.zeros_like(vel))                         # an independent copy: the positions stay
         s.step(1.0, 1e-3)
         acc = s.download()[1][:, :3].astype(np.float64)
