@@ -823,8 +823,8 @@ hipError_t launch_forces(const ForceArgs &a, int rows_per_lane, hipStream_t stre
 // The splits' partial sums of row r, added in ascending split order (one fp32 chain: the order defines the bits).  The
 // loads of 16 splits are issued together and the adds follow in order: a lane's loads are independent, its adds are not,
 // and with few rows (the reference's N = 20 000: 79 splits x 20 225 rows, 80 workgroups of 256) the kernel is bound by
-// load latency, not bandwidth -- 21.7 us with one load in flight per lane, profiles/r03_small_n_kernels.txt.  BATCH = 32 for
-// the one-wave update workgroups of small systems (a few hundred waves on the chip: registers are free, round trips are not).
+// load latency, not bandwidth -- 21.7 us with one load in flight per lane, profiles/r03_small_n_kernels.txt.  (32 at a time
+// measured slower: 13.7 against 11.0 us at N = 20 225.)
 template <int BATCH = 16>
 __device__ __forceinline__ float4 sum_partials(const float4 *partials, int r, int row_count, int n_splits)
 {
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(BLOCK) void update_kernel(float4 *pos_all, float4 *
     const int r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= row_count)
         return;
-    const float4 acc = sum_partials<BLOCK == 64 ? 32 : 16>(partials, r, row_count, n_splits);
+    const float4 acc = sum_partials(partials, r, row_count, n_splits);
     float4 v = vel_rows[r];
     float4 x = pos_all[row_lo + r];
     const double h = (double)dt;
