@@ -47,6 +47,7 @@ _PROTOTYPES = {
     "nbody_step_n": (c_int, [c_void_p, c_int, c_float, c_float]),
     "nbody_step_n_on": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float]),
     "nbody_set_graph_replay": (c_int, [c_void_p, c_int]),
+    "nbody_set_strip_len": (c_int, [c_void_p, c_int]),
     "nbody_sync": (c_int, [c_void_p]),
     "nbody_forces": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "nbody_forces_complement": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),

@@ -26,6 +26,8 @@ struct nbody_ctx {
     bool equal_mass_path = true;  // splits whose bodies share one mass take the inner loop without mass multiplies
     int sum_parts = 0;  // pair-once mode, one context: launches the row groups are cut into (nbody_set_summation_parts)
     int force_mode = NBODY_FORCE_ONE_SIDED;
+    int strip_setting = 0;  // nbody_set_strip_len: 0 = automatic
+    int strip_len = 1;      // pair-once mode: column splits a tile workgroup takes with the rows' sums kept in registers (SymArgs)
     int integrator = NBODY_INTEGRATOR_KICK_DRIFT;
     float4 *acc = nullptr;      // kick-drift-kick mode: accelerations of the own rows at the current positions
     bool acc_valid = false;
@@ -39,7 +41,8 @@ struct nbody_ctx {
         int g0 = 0, g1 = 0;              // row groups [g0, g1)
         int split_lo = 0, split_hi = 0;  // = row splits [split_lo, split_hi)
         int64_t b0 = 0, rows = 0;        // = rows [b0, b0 + rows) of this context
-        int2 *tiles = nullptr, *diag = nullptr;
+        int4 *tiles = nullptr;  // strips {R, first C, count, slot}
+        int2 *diag = nullptr;
         int n_tiles = 0, n_diag = 0;
         size_t row_off = 0, col_off = 0;  // where the part's [n_splits/2+1][rows] and [splits][n_splits/2][split_len] arrays
                                           // start in partials / col_partials, in 12-byte entries
@@ -723,6 +726,8 @@ static int resplit(nbody_ctx *c, int64_t split_len)
     return NBODY_OK;
 }
 
+static int sym_strip_len(const nbody_ctx *c);
+
 int nbody_set_force_mode(nbody_ctx *c, int mode)
 {
     if (!c || (mode != NBODY_FORCE_ONE_SIDED && mode != NBODY_FORCE_SYMMETRIC && mode != NBODY_FORCE_AUTO))
@@ -759,6 +764,7 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
         c->group_splits = gs;
         c->group_lo = split_lo / gs;
         c->group_count = c->row_count ? (split_hi + gs - 1) / gs - c->group_lo : 0;
+        c->strip_len = sym_strip_len(c);
         HIP_TRY(c, hipSetDevice(c->device));
         if (!c->sym_acc && c->row_count)
             HIP_TRY(c, hipMalloc((void **)&c->sym_acc, sizeof(float4) * (size_t)c->row_count));
@@ -782,6 +788,36 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
     clear_split_done(c);
     c->acc_valid = false;
     drop_step_graph(c);
+    return NBODY_OK;
+}
+
+// Strips (SymArgs, nbody_kernels.h): from the 2048-body splits on -- N >= 2^20, where the partial sums are gigabytes -- a tile
+// workgroup takes four consecutive column splits of its row split and keeps the rows' sums in registers across them: a quarter
+// of the row-side partial sums (N = 2^20: 0.8 instead of 3.2 GB per pass; the column side keeps its 3.2 GB -- halving that as well
+// takes a workgroup that owns a whole CU, measured 7 % slower: profiles/r04_ab_whole_cu_workgroup.txt).  The blocks of four are
+// absolute and the number of splits must be a multiple of 8 x 4, so no strip straddles a summation group or a rank's column
+// chunk and which sums exist stays a function of (n_total, split_len) alone; other split counts keep single tiles.
+static int sym_strip_len(const nbody_ctx *c)
+{
+    const int want = c->strip_setting ? c->strip_setting : (c->split_len >= 2048 ? 4 : 1);
+    return want > 1 && c->n_splits % (kSymGroups * want) == 0 && c->split_len == 2048 ? want : 1;
+}
+
+int nbody_set_strip_len(nbody_ctx *c, int len)
+{
+    if (!c || !(len == 0 || len == 1 || len == 2 || len == 4 || len == 8))
+        return fail(c, NBODY_ERR_INVALID, "nbody_set_strip_len: expected 0 (automatic), 1, 2, 4 or 8");
+    if (c->strip_setting != len) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+        free_sym_tiles(c);  // the cached plans carry the strips
+        clear_split_done(c);
+    }
+    c->strip_setting = len;
+    if (c->force_mode == NBODY_FORCE_SYMMETRIC)
+        c->strip_len = sym_strip_len(c);
+    c->acc_valid = false;
     return NBODY_OK;
 }
 
@@ -852,7 +888,7 @@ int nbody_sym_rowsum(nbody_ctx *c)
     const nbody_ctx::SymPart &p = *c->pending;
     HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + p.row_off, c->rowsum + p.b0,
                                  (int)(c->row_lo + p.b0), (int)p.rows, (int)c->split_len, c->n_splits, c->group_splits,
-                                 (int)c->row_count, c->stream));
+                                 (int)c->row_count, c->strip_len, c->stream));
     c->sym_rows_summed = true;
     return NBODY_OK;
 }
@@ -1086,6 +1122,10 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 if (c->split_done[(size_t)sp])
                     return fail(c, NBODY_ERR_STATE, std::string(who) + ": a column range after a call for all columns in several "
                                                                         "summation parts: the earlier parts are already summed");
+        const int SL = c->strip_len;
+        if (SL > 1 && (first % SL != 0 || ((first + count) % SL != 0 && first + count != S)))
+            return fail(c, NBODY_ERR_INVALID, std::string(who) + ": with strips of " + std::to_string(SL) + " column splits a column "
+                                                                  "range must start and end on a multiple of that many splits");
         auto key = std::make_tuple(first, count, complement);
         auto it = c->sym_plans.find(key);
         if (it == c->sym_plans.end()) {
@@ -1095,17 +1135,27 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             // instead of 128; workgroups are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md), so block k's tiles
             // take the launch slots congruent to k mod 8 and meet in one XCD's L2.
             const int B = 8;
-            auto list_rows = [&](int r_lo, int r_hi) {  // the tiles with a row split in [r_lo, r_hi), in launch order
-                std::vector<int2> tiles;
-                std::vector<std::vector<int2>> per_xcd(8);
+            auto list_rows = [&](int r_lo, int r_hi) {  // the strips with a row split in [r_lo, r_hi), in launch order
+                std::vector<int4> tiles;
+                std::vector<std::vector<int4>> per_xcd(8);
+                const int n_blocks = S / SL;  // SL = 1: a "block" is one column split, a strip one tile, its slot the ring distance
                 int k = 0;
                 for (int Rb = r_lo; Rb < r_hi; Rb += B)
-                    for (int db = 1; db <= S / 2; db += B, ++k)
+                    for (int jb = 0; jb <= n_blocks / 2 + 1; jb += B, ++k)
                         for (int R = Rb; R < std::min(Rb + B, r_hi); ++R)
-                            for (int d = db; d < std::min(db + B, S / 2 + 1); ++d) {
-                                const int C = (R + d) % S;
-                                if (selected(C) && sym_rows_side(R, C, S))
-                                    per_xcd[(size_t)k % per_xcd.size()].push_back(make_int2(R, C));
+                            for (int j = jb; j < std::min(jb + B, n_blocks / 2 + 2); ++j) {
+                                const int J = (((R + 1) % S) / SL + j) % n_blocks;  // the j-th block along the ring from R + 1
+                                int C0 = -1, cnt = 0;
+                                for (int C = J * SL; C < (J + 1) * SL; ++C)
+                                    if (selected(C) && sym_rows_side(R, C, S)) {
+                                        if (cnt == 0)
+                                            C0 = C;
+                                        ++cnt;
+                                    }
+                                // a block met twice along the ring (its head at the start of the half ring, its tail at the end)
+                                // cannot happen: the half ring is shorter than the ring by far more than a block
+                                if (cnt > 0)
+                                    per_xcd[(size_t)k % per_xcd.size()].push_back(make_int4(R, C0, cnt, sym_row_slot(R, C0, S, SL)));
                             }
                 for (size_t j = 0, more = 1; more; ++j) {
                     more = 0;
@@ -1115,6 +1165,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                             more = 1;
                         }
                 }
+                // whole strips first, the shorter ones of the band's edges behind them: the launch's tail is made of short workgroups
+                std::stable_partition(tiles.begin(), tiles.end(), [&](const int4 &t) { return t.z == SL; });
                 return tiles;
             };
             // Summation parts (one context that owns every row, all columns in one call, a system large enough for several
@@ -1125,7 +1177,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             const int n_groups = (S + c->group_splits - 1) / c->group_splits;
             int K = c->sum_parts;
             if (K == 0) {  // automatic: one launch is the fastest (profiles/r02_summation_parts_eight_rows.txt); more only for memory
-                const double pass_bytes = 12.0 * (double)c->n_total * (double)c->n_total / (double)L;
+                // the column side and the row side (a strip's rows are summed in registers: 1 / strip_len of the entries)
+                const double pass_bytes = 6.0 * (double)c->n_total * (double)c->n_total / (double)L * (1.0 + 1.0 / (double)SL);
                 // 4 parts of 3 + 3 + 1 + 1 groups hold two slots of three groups = 3/4 of the pass; 8 equal parts a quarter
                 K = pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 1 : 0.75 * pass_bytes <= (double)NBODY_PARTIAL_SUM_BUDGET_BYTES ? 4 : 8;
             }
@@ -1160,7 +1213,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 part.split_hi = std::min(own_hi, part.g1 * c->group_splits);
                 part.b0 = (int64_t)part.split_lo * L - c->row_lo;
                 part.rows = std::min<int64_t>((int64_t)part.split_hi * L, c->row_lo + c->row_count) - (int64_t)part.split_lo * L;
-                const size_t row_need = ((size_t)S / 2 + 1) * (size_t)part.rows;
+                const size_t row_need = (size_t)sym_row_slots(S, SL) * (size_t)part.rows;
                 const size_t col_need = (size_t)(part.split_hi - part.split_lo) * (size_t)(S / 2) * (size_t)L;
                 if (K > 2) {  // two slots used in turn
                     plan.row_entries = std::max(plan.row_entries, 2 * row_need);
@@ -1171,14 +1224,15 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                     plan.row_entries += row_need;
                     plan.col_entries += col_need;
                 }
-                std::vector<int2> tiles = list_rows(part.split_lo, part.split_hi), diag;
+                std::vector<int4> tiles = list_rows(part.split_lo, part.split_hi);
+                std::vector<int2> diag;
                 for (int R = part.split_lo; R < part.split_hi; ++R)
                     if (selected(R))
                         diag.push_back(make_int2(R, R));
                 HIP_TRY(c, hipSetDevice(c->device));
                 if (!tiles.empty()) {
-                    HIP_TRY(c, hipMalloc((void **)&part.tiles, sizeof(int2) * tiles.size()));
-                    HIP_TRY(c, hipMemcpy(part.tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(c, hipMalloc((void **)&part.tiles, sizeof(int4) * tiles.size()));
+                    HIP_TRY(c, hipMemcpy(part.tiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice));
                 }
                 if (!diag.empty()) {
                     HIP_TRY(c, hipMalloc((void **)&part.diag, sizeof(int2) * diag.size()));
@@ -1224,6 +1278,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             sa.col_partials = c->col_partials + p.col_off;
             sa.tiles = p.tiles;
             sa.n_tiles = p.n_tiles;
+            sa.strip_len = c->strip_len;
             sa.diag_tiles = p.diag;
             sa.n_diag = p.n_diag;
             sa.row_lo = (int)(c->row_lo + p.b0);
@@ -1275,7 +1330,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                                                c->group_splits, part.g0, part.g1 - part.g0, c->aux_stream));
                 HIP_TRY(c, launch_sym_rowsum(reinterpret_cast<const float3 *>(c->partials) + part.row_off, c->rowsum + part.b0,
                                              (int)(c->row_lo + part.b0), (int)part.rows, L, S, c->group_splits, (int)c->row_count,
-                                             c->aux_stream));
+                                             c->strip_len, c->aux_stream));
             }
             HIP_TRY(c, hipEventRecord(c->ev_red[(size_t)p], c->aux_stream));
             if (p + 2 < K)
@@ -1370,7 +1425,7 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
         constexpr int fused_max_splits = 320;
         if (c->force_mode == NBODY_FORCE_SYMMETRIC && c->row_lo == 0 && c->row_count == c->n_total && c->pending &&
             !c->sym_reduced && !c->sym_rows_summed && c->pending->g1 - c->pending->g0 == c->group_count &&
-            c->pending->row_off == 0 && c->pending->col_off == 0 && c->n_splits <= fused_max_splits) {
+            c->pending->row_off == 0 && c->pending->col_off == 0 && c->n_splits <= fused_max_splits && c->strip_len == 1) {
             int rc = all_splits_done(c, "nbody_update");
             if (rc != NBODY_OK)
                 return rc;

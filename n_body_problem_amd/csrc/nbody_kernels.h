@@ -57,16 +57,34 @@ __host__ __device__ inline bool sym_rows_side(int R, int C, int S)
     return ((lo & 1) == 0) == (R == lo);
 }
 
+// Strips (round 4).  A workgroup takes `strip_len` = K consecutive column splits of one row split -- the splits C with equal
+// C / K that form a tile with R (K = 1: every tile alone, rounds 1-3) -- and keeps the rows' sums in registers across them: one
+// row-side partial sum per (row, strip) instead of per (row, tile).  The strip that holds column split C is slot
+// sym_row_slot(R, C) of the row split's array: the blocks of K splits are counted along the ring from the block of R + 1 (K = 1:
+// the ring distance of the tile, the layout of rounds 1-3); slot 0 is the diagonal tile.  Blocks are absolute (C / K), the
+// number of splits is a multiple of 8 K, so a strip never straddles a summation group or a rank's column chunk: which sums
+// exist and in which order they are added is a function of (n_total, split_len) only, as before.
+__host__ __device__ inline int sym_row_slot(int R, int C, int S, int K)
+{
+    int j = C / K - ((R + 1) % S) / K;
+    if (j < 0)
+        j += S / K;
+    return j + 1;
+}
+__host__ __device__ inline int sym_row_slots(int S, int K) { return K == 1 ? S / 2 + 1 : S / (2 * K) + 3; }
+
 struct SymArgs {
     const float4 *pos;     // all n_total bodies
     // Both arrays are indexed by the ring distance d = (C - R) mod S of the tile, 0 <= d <= S/2 (0: the diagonal), so
     // they hold exactly the partial sums that exist:
     // (12-byte entries {x, y, z}: a quarter fewer bytes than float4 for the 2 x n_total^2 / split_len entries a step writes
     // and the summation kernels read back)
-    float3 *row_partials;  // [S/2 + 1][row_count]: P_row[d][b] = force on own body b (split R) from the bodies of split R + d
+    float3 *row_partials;  // [sym_row_slots][row_count]: P_row[slot][b] = force on own body b (split R) from the bodies of the strip
+                           // in that slot (strip_len 1: slot = d, the bodies of split R + d)
     float3 *col_partials;  // [own splits][S/2][split_len]: P_col[R][d - 1][i] = force on body i of split R + d from own split R
-    const int2 *tiles;     // n_tiles pairs (R, C), R an own split, R != C
+    const int4 *tiles;     // n_tiles strips {R, first C, count, slot}: R an own split, C ... C + count - 1 its column splits
     int n_tiles;
+    int strip_len;         // K
     const int2 *diag_tiles;  // n_diag pairs (B, B), own splits: every pair inside the split once, both sides
     int n_diag;
     int n_total;
@@ -93,7 +111,7 @@ hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int
 // P_row[d(B, C)][b] for the rows [row_lo, row_lo + row_count) that row_partials ([n_splits/2+1][row_count]) holds; rowsum
 // points at the first of them in a [groups][out_stride] float4 array.
 hipError_t launch_sym_rowsum(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count, int split_len, int n_splits,
-                             int group_splits, int out_stride, hipStream_t stream);
+                             int group_splits, int out_stride, int strip_len, hipStream_t stream);
 // acc[b] = sum over the groups g (ascending) of ( rowsum[g][b] + colparts[g][b] ): the same association for any number of ranks.
 hipError_t launch_sym_combine(const float4 *rowsum, const float4 *colparts, float4 *acc, int row_lo, int row_count, int n_total,
                               int n_groups, hipStream_t stream);

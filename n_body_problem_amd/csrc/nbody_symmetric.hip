@@ -652,31 +652,67 @@ typedef float nb_f16 __attribute__((ext_vector_type(16)));
 #ifndef NB_S8_WAVES
 #define NB_S8_WAVES 4  /* waves per SIMD the eight-row equal-mass kernel is allocated for */
 #endif
-template <int W, bool GUARD, int ROWS8 = 0>
+// MODE 0: every strip is one tile (strip_len 1: the launcher's promise) -- the kernel of rounds 1-3.
+// MODE 1 (ROWS8 = 2, 3 only): the split is ONE pass of the eight-row loops (split_len = 512 rows x W, the launcher's promise), so
+// the rows and their sums stay in registers across the strip's tiles -- one chain per row over all the strip's columns -- and
+// the strip takes one kind of loop.
+// MODE 2: the strip's tiles are served one after the other and each tile's row sums are added to the strip's in memory (the
+// kernels that cannot keep the rows: eps = 0, the four-row loops; A/B arrangements).
+template <int W, bool GUARD, int ROWS8 = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 == 4 ? 4 : ROWS8 >= 2 ? 3 : ROWS8 == 1 ? NB_S8_WAVES : 5))) void force_sym_kernel(SymArgs a)  // ROWS8 = 0: <= 96 VGPRs
 {
+    constexpr bool STRIP = MODE == 1;
+    static_assert(!STRIP || ((ROWS8 == 2 || ROWS8 == 3) && !GUARD), "rows stay in registers only in the eight-row kernels");
     constexpr int kSymThreads = 64 * W, kSymWaves = W, kSymRowsPerPass = W * 64 * kSymRows;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int L = a.split_len, G = L / 64;
     const SymLds lds = sym_lds<W>(smem, L);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int2 t = a.tiles[blockIdx.x];
-    const int rowbase = t.x * L, colbase = t.y * L;
+    const int4 t = a.tiles[blockIdx.x];  // the strip {R, first C, count, slot}: count tiles (R, C), (R, C + 1), ... of one row split
+    const int rowbase = t.x * L;
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
     const int row_hi = min(a.row_lo + a.row_count, a.n_total);
     const int S = (a.n_total + L - 1) / L;
     // the one mass of the row split's / column split's bodies, NaN where they differ (split_mass_kernel): workgroup-uniform
-    const float mass_rows = GUARD ? __builtin_nanf("") : a.split_mass[t.x], mass_cols = GUARD ? mass_rows : a.split_mass[t.y];
-    // ... and only when every pass is full: the lanes of a partial last pass (split lengths that are not a multiple of the
-    // rows per pass, e.g. 768 with two waves) carry dummy rows whose zero MASS is what keeps them out of the column sums
-    const bool uniform = ROWS8 <= 3 && !GUARD && mass_rows == mass_rows && mass_cols == mass_cols && L % kSymRowsPerPass == 0;  // 4: masses in the loop
-    const float row_scale = uniform ? mass_cols : 1.f, col_scale = uniform ? mass_rows : 1.f;
+    const float mass_rows = GUARD ? __builtin_nanf("") : a.split_mass[t.x];
+    // the tile at hand (tile_at): its column split, its columns' one mass, and whether it takes the equal-mass loops --
+    // only when every pass is full: the lanes of a partial last pass (split lengths that are not a multiple of the rows per pass,
+    // e.g. 768 with two waves) carry dummy rows whose zero MASS is what keeps them out of the column sums
+    struct Tile {
+        int C, colbase;
+        float mass_cols, row_scale, col_scale;
+        bool uniform;
+        bool accumulate;  // MODE 2: the tile's row sums are ADDED to the strip's (tiles after the first)
+    };
+    auto tile_at = [&](int c, bool accumulate) {
+        Tile tl;
+        tl.C = c;
+        tl.colbase = c * L;
+        tl.mass_cols = GUARD ? mass_rows : a.split_mass[c];
+        tl.uniform = ROWS8 <= 3 && !GUARD && mass_rows == mass_rows && tl.mass_cols == tl.mass_cols && L % kSymRowsPerPass == 0;  // 4: masses in the loop
+        tl.row_scale = tl.uniform ? tl.mass_cols : 1.f;
+        tl.col_scale = tl.uniform ? mass_rows : 1.f;
+        tl.accumulate = accumulate;
+        return tl;
+    };
 
     for (int c = tid; c < L; c += kSymThreads)
         lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
     __syncthreads();
+    // the tile's column sums out of LDS -- P_col[R][d - 1][.] -- and LDS cleared for the next tile of the strip
+    auto write_columns = [&](const Tile tl) {
+        float3 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, tl.C, S), S, L);
+        for (int c = tid; c < L; c += kSymThreads) {
+            if (tl.colbase + c < a.n_total)
+                out[c] = make_float3(lds.sx[c] * tl.col_scale, lds.sy[c] * tl.col_scale, lds.sz[c] * tl.col_scale);
+            if (MODE != 0)
+                lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
+        }
+        if (MODE != 0)
+            __syncthreads();
+    };
 
-    auto passes = [&](auto variant_tag) {  // one copy of the loops per inner-loop variant: no merged live ranges
+    auto passes = [&](auto variant_tag, const Tile tl) {  // one copy of the loops per inner-loop variant: no merged live ranges
     // 0 general masses, 1 equal-mass tile (one column per step); packed, two columns per step: 2 equal-mass tile, 3 general masses,
     // 4 general masses + per-particle softening
     constexpr int VARIANT = decltype(variant_tag)::value;
@@ -707,7 +743,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
         float4 cnext = zero4;  // the next group's column bodies, loaded a group ahead
         float enext = 0.f;     // PPS4: and their softening lengths
         {
-            const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + lane;
+            const int gc = tl.colbase + sym_group(0, wave, spacing, G) * 64 + lane;
             if (gc < a.n_total) {
                 cnext = a.pos[gc];
                 if (PPS4)
@@ -733,7 +769,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
                 lds.stage[lane] = cnext;
             }
             if (g + 1 < G) {
-                const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + lane;
+                const int gc = tl.colbase + sym_group(g + 1, wave, spacing, G) * 64 + lane;
                 cnext = zero4;
                 enext = 0.f;
                 if (gc < a.n_total) {
@@ -860,20 +896,28 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
         }
         __syncthreads();
 
-        float3 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // row sums: P_row[d][row]
+        float3 *const row_out = a.row_partials + (size_t)t.w * a.row_count;  // the strip's row sums: P_row[slot][row]
 #pragma unroll
         for (int k = 0; k < kSymRows; ++k) {
             const int r = pass0 + (wave * kSymRows + k) * 64 + lane;
-            if (r < L && rowbase + r < row_hi)
-                out[rowbase + r - a.row_lo] = PACKED ? make_float3((ra[k][0].x + ra[k][0].y) * row_scale,
-                                                                          (ra[k][1].x + ra[k][1].y) * row_scale,
-                                                                          (ra[k][2].x + ra[k][2].y) * row_scale)
-                                                           : make_float3(ax[k] * row_scale, ay[k] * row_scale, az[k] * row_scale);
+            if (r < L && rowbase + r < row_hi) {
+                float3 v = PACKED ? make_float3((ra[k][0].x + ra[k][0].y) * tl.row_scale, (ra[k][1].x + ra[k][1].y) * tl.row_scale,
+                                                (ra[k][2].x + ra[k][2].y) * tl.row_scale)
+                                  : make_float3(ax[k] * tl.row_scale, ay[k] * tl.row_scale, az[k] * tl.row_scale);
+                if (MODE == 2 && tl.accumulate) {  // the same lane wrote the strip's sums so far
+                    const float3 o = row_out[rowbase + r - a.row_lo];
+                    v = make_float3(o.x + v.x, o.y + v.y, o.z + v.z);
+                }
+                row_out[rowbase + r - a.row_lo] = v;
+            }
         }
     }
     };
     // eight rows per lane (S8_GROUP_LOOP: equal-mass tiles; S9_GROUP_LOOP: arbitrary masses): a wave owns 512 rows of a pass
-    auto passes8 = [&](auto general_tag) {
+    // STRIP: the strip's tiles inside (the rows and their sums stay in registers); otherwise the lambda serves the tile at hand.
+    auto passes8 = [&](auto general_tag, const Tile tl) {
+        constexpr bool own_strip = STRIP;
+        Tile cur = tl;  // the tile at hand (STRIP: it advances along the strip; the loop and the scales are the strip's)
         // 0: equal-mass tile (S8), 1: arbitrary masses (S9), 2: arbitrary masses + per-particle softening (S10), 3: equal-mass tile +
         // per-particle softening (S12)
         constexpr int VARIANT8 = decltype(general_tag)::value;
@@ -906,10 +950,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
             const nb_f2 xy4 = {p[4].x, p[4].y}, xy5 = {p[5].x, p[5].y}, xy6 = {p[6].x, p[6].y}, xy7 = {p[7].x, p[7].y};
             const nb_f2 m01 = {p[0].w, p[1].w}, m23 = {p[2].w, p[3].w}, m45 = {p[4].w, p[5].w}, m67 = {p[6].w, p[7].w};  // GENERAL
             nb_f16 ra0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+            for (int ti = 0, n_tiles_here = own_strip ? t.z : 1; ti < n_tiles_here; ++ti) {
+            if (own_strip) {  // the strip's next tile: same rows, same loop (the strip takes ONE kind of loop, see below)
+                cur.C = t.y + ti;
+                cur.colbase = cur.C * L;
+            }
             float4 cnext = zero4;  // the next group's column bodies, loaded a group ahead
             float enext = 0.f;     // PPS8: and their softening lengths
             {
-                const int gc = colbase + sym_group(0, wave, spacing, G) * 64 + sl;
+                const int gc = cur.colbase + sym_group(0, wave, spacing, G) * 64 + sl;
                 if (gc < a.n_total) {
                     cnext = a.pos[gc];
                     if (PPS8)
@@ -927,7 +976,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
                 if (PPS8)
                     estage8[lane] = estage8[64 + lane] = enext * enext;
                 if (g + 1 < G) {
-                    const int gc = colbase + sym_group(g + 1, wave, spacing, G) * 64 + sl;
+                    const int gc = cur.colbase + sym_group(g + 1, wave, spacing, G) * 64 + sl;
                     cnext = zero4;
                     enext = 0.f;
                     if (gc < a.n_total) {
@@ -994,7 +1043,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
                     __syncthreads();
             }
             __syncthreads();
-            float3 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // row sums: P_row[d][row]
+            if (own_strip)
+                write_columns(cur);
+            }
+            float3 *const row_out = a.row_partials + (size_t)t.w * a.row_count;  // the strip's row sums: P_row[slot][row]
             float sum[48];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1005,50 +1057,79 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int r = pass0 + (wave * 8 + k) * 64 + sl;
-                if (r < L && rowbase + r < row_hi)
-                    out[rowbase + r - a.row_lo] = make_float3((sum[6 * k] + sum[6 * k + 1]) * row_scale,
-                                                              (sum[6 * k + 2] + sum[6 * k + 3]) * row_scale,
-                                                              (sum[6 * k + 4] + sum[6 * k + 5]) * row_scale);
+                if (r < L && rowbase + r < row_hi) {
+                    float3 v = make_float3((sum[6 * k] + sum[6 * k + 1]) * cur.row_scale, (sum[6 * k + 2] + sum[6 * k + 3]) * cur.row_scale,
+                                           (sum[6 * k + 4] + sum[6 * k + 5]) * cur.row_scale);
+                    if (MODE == 2 && tl.accumulate) {
+                        const float3 o = row_out[rowbase + r - a.row_lo];
+                        v = make_float3(o.x + v.x, o.y + v.y, o.z + v.z);
+                    }
+                    row_out[rowbase + r - a.row_lo] = v;
+                }
             }
         }
     };
-    bool done = false;
-    if constexpr (ROWS8 != 0 && !GUARD) {
-        if (L % (kSymThreads * 8) == 0) {  // whole passes of 512 rows per wave (dummy rows would need their zero mass: see above)
-            if constexpr (ROWS8 == 3) {
-                if (uniform)
-                    passes8(std::integral_constant<int, 3>{});
-                else
-                    passes8(std::integral_constant<int, 2>{});
-                done = true;
-            } else if (uniform) {
-                passes8(std::integral_constant<int, 0>{});
-                done = true;
-            } else if constexpr (ROWS8 == 2) {
-                passes8(std::integral_constant<int, 1>{});
-                done = true;
+    // The strip.  Where the split is one pass of the eight-row loops (L = 512 rows x waves: 2048-body splits with four waves, the
+    // splits of N >= 2^20) the rows' sums stay in registers across the strip's tiles and the strip takes ONE loop: the equal-mass
+    // one when the row split carries one mass and every column split of the strip carries one and the same mass (every strip of
+    // the benchmark's sphere), else the loop with the masses in it.  Elsewhere the tiles are served one after the other and each
+    // tile's row sums are added to the strip's (accumulate): a function of the data and the split boundaries either way.
+    if constexpr (STRIP) {
+        Tile tl = tile_at(t.y, false);
+        bool strip_uniform = tl.uniform;
+        for (int ti = 1; ti < t.z; ++ti)
+            strip_uniform = strip_uniform && a.split_mass[t.y + ti] == tl.mass_cols;  // NaN (mixed masses) compares unequal
+        tl.uniform = strip_uniform;
+        tl.row_scale = strip_uniform ? tl.mass_cols : 1.f;
+        tl.col_scale = strip_uniform ? mass_rows : 1.f;
+        if constexpr (ROWS8 == 3) {
+            if (tl.uniform)
+                passes8(std::integral_constant<int, 3>{}, tl);
+            else
+                passes8(std::integral_constant<int, 2>{}, tl);
+        } else if (tl.uniform) {
+            passes8(std::integral_constant<int, 0>{}, tl);
+        } else {
+            passes8(std::integral_constant<int, 1>{}, tl);
+        }
+        return;
+    }
+    for (int ti = 0; ti < (MODE == 2 ? t.z : 1); ++ti) {
+        const Tile tl = tile_at(t.y + ti, ti > 0);
+        bool done = false;
+        if constexpr (ROWS8 != 0 && !GUARD) {
+            if (L % (kSymThreads * 8) == 0) {  // whole passes of 512 rows per wave (dummy rows would need their zero mass: see above)
+                if constexpr (ROWS8 == 3) {
+                    if (tl.uniform)
+                        passes8(std::integral_constant<int, 3>{}, tl);
+                    else
+                        passes8(std::integral_constant<int, 2>{}, tl);
+                    done = true;
+                } else if (tl.uniform) {
+                    passes8(std::integral_constant<int, 0>{}, tl);
+                    done = true;
+                } else if constexpr (ROWS8 == 2) {
+                    passes8(std::integral_constant<int, 1>{}, tl);
+                    done = true;
+                }
             }
         }
+        if constexpr (ROWS8 == 4 && !GUARD) {  // per-particle softening, four rows per lane: the only loop of this instantiation
+            passes(std::integral_constant<int, 4>{}, tl);
+        } else {
+            if (done)
+                ;
+            else if (tl.uniform && a.packed)
+                passes(std::integral_constant<int, 2>{}, tl);
+            else if (tl.uniform)
+                passes(std::integral_constant<int, 1>{}, tl);
+            else if (!GUARD && a.packed)
+                passes(std::integral_constant<int, 3>{}, tl);
+            else
+                passes(std::integral_constant<int, 0>{}, tl);
+        }
+        write_columns(tl);
     }
-    if constexpr (ROWS8 == 4 && !GUARD) {  // per-particle softening, four rows per lane: the only loop of this instantiation
-        passes(std::integral_constant<int, 4>{});
-    } else {
-        if (done)
-            ;
-        else if (uniform && a.packed)
-            passes(std::integral_constant<int, 2>{});
-        else if (uniform)
-            passes(std::integral_constant<int, 1>{});
-        else if (!GUARD && a.packed)
-            passes(std::integral_constant<int, 3>{});
-        else
-            passes(std::integral_constant<int, 0>{});
-    }
-
-    float3 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);  // P_col[R][d-1][.]
-    for (int c = tid; c < L; c += kSymThreads)
-        if (colbase + c < a.n_total)
-            out[c] = make_float3(lds.sx[c] * col_scale, lds.sy[c] * col_scale, lds.sz[c] * col_scale);
 }
 
 // split_mass[s] = the mass every body of split s has, or NaN when they differ (a ragged last split counts its missing
@@ -1104,8 +1185,10 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
     const SymLds lds = sym_lds<W>(smem, L);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *estage = lds.sz + L + wave * 128;  // 128 floats per wave are reserved (the eight-row loop stages the group twice)
-    const int2 t = DIAG ? a.diag_tiles[blockIdx.x] : a.tiles[blockIdx.x];
-    const int rowbase = t.x * L, colbase = t.y * L;
+    // DIAG: one diagonal tile (B, B); else a strip {R, first C, count, slot}, its tiles served one after the other and the row
+    // sums of the tiles after the first ADDED to the strip's (the same lanes wrote them)
+    const int4 t = DIAG ? make_int4(a.diag_tiles[blockIdx.x].x, a.diag_tiles[blockIdx.x].y, 1, 0) : a.tiles[blockIdx.x];
+    const int rowbase = t.x * L;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int spacing = G >= kSymWaves ? G / kSymWaves : 1;
     const int row_hi = min(a.row_lo + a.row_count, a.n_total);
@@ -1117,6 +1200,8 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
         lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
     __syncthreads();
 
+    for (int ti = 0; ti < t.z; ++ti) {
+    const int C = t.y + ti, colbase = C * L;
     for (int pass0 = 0; pass0 < L; pass0 += kSymRowsPerPass) {
         float x[kSymRows], y[kSymRows], z[kSymRows], m[kSymRows], ax[kSymRows], ay[kSymRows], az[kSymRows], er[kSymRows];
         int rl[kSymRows];  // row index inside the split, or -1
@@ -1199,22 +1284,34 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
                 }
             __syncthreads();
         } else {
-            float3 *out = a.row_partials + (size_t)sym_distance(t.x, t.y, S) * a.row_count;  // P_row[d][row]
+            float3 *out = a.row_partials + (size_t)t.w * a.row_count;  // P_row[slot][row]
 #pragma unroll
             for (int k = 0; k < kSymRows; ++k)
-                if (rl[k] >= 0)
-                    out[rowbase + rl[k] - a.row_lo] = make_float3(ax[k], ay[k], az[k]);
+                if (rl[k] >= 0) {
+                    float3 v = make_float3(ax[k], ay[k], az[k]);
+                    if (ti > 0) {
+                        const float3 o = out[rowbase + rl[k] - a.row_lo];
+                        v = make_float3(o.x + v.x, o.y + v.y, o.z + v.z);
+                    }
+                    out[rowbase + rl[k] - a.row_lo] = v;
+                }
         }
     }
 
-    // DIAG: both sides of the split, P_row[0][b]; else the column sums, P_col[R][d-1][.]
+    // DIAG: both sides of the split, P_row[0][b]; else the tile's column sums, P_col[R][d-1][.], and LDS cleared for the next tile
     float3 *out = DIAG ? a.row_partials + (rowbase - a.row_lo)
-                       : sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, t.y, S), S, L);
+                       : sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, C, S), S, L);
     const int col_hi = DIAG ? row_hi : a.n_total;  // a diagonal tile's columns are the context's own rows
-    for (int c = tid; c < L; c += kSymThreads)
+    for (int c = tid; c < L; c += kSymThreads) {
         if (colbase + c < col_hi)
             out[c] = make_float3(lds.sx[c], lds.sy[c], lds.sz[c]);
+        lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
+    }
+    __syncthreads();
+    }
 }
+
+
 
 // waves per tile workgroup: W x 256 rows per pass must not exceed the split
 static int sym_waves(int split_len) { return split_len >= 1024 ? 4 : split_len >= 512 ? 2 : 1; }
@@ -1261,6 +1358,17 @@ static size_t sym_lds_bytes_for(int waves, int split_len)
 template <int W>
 static hipError_t sym_launch_tiles(const SymArgs &a, size_t lds, hipStream_t stream)
 {
+    if constexpr (W == 4) {
+        if (a.strip_len > 1) {  // the kernels that cannot keep a strip's rows in registers add its tiles' row sums in memory
+            if (a.eps_pp && a.eps2 > 0.f && a.packed >= 2)
+                return sym_launch(&force_sym_kernel<4, false, 4, 2>, a.n_tiles, 4, lds, a, stream);
+            if (a.eps_pp)
+                return a.eps2 > 0.f ? sym_launch(&force_sym_general_kernel<4, false, false, true>, a.n_tiles, 4, lds, a, stream)
+                                    : sym_launch(&force_sym_general_kernel<4, false, true, true>, a.n_tiles, 4, lds, a, stream);
+            return a.eps2 > 0.f ? sym_launch(&force_sym_kernel<4, false, 0, 2>, a.n_tiles, 4, lds, a, stream)
+                                : sym_launch(&force_sym_kernel<4, true, 0, 2>, a.n_tiles, 4, lds, a, stream);
+        }
+    }
     // per-particle softening: the four-row loop S11 with eps > 0; with eps = 0 a particle may have eps_i = 0 too and the guarded,
     // compiler-scheduled kernel runs (NBODY_SYM_PACKED=0 / rows_per_lane 4: that kernel always -- A/B, tests)
     if (a.eps_pp && a.eps2 > 0.f && a.packed >= 2)
@@ -1290,6 +1398,10 @@ hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
     if (a.packed >= 2 && a.eps_pp && a.eps2 > 0.f && a.split_len % 512 == 0) {  // per-particle softening: the eight-row loop S10
         const int w8 = a.split_len % 2048 == 0 ? 4 : a.split_len % 1024 == 0 ? 2 : 1;  // whole passes of 512 rows per wave
         const size_t lds8 = sym_lds_bytes_for(w8, a.split_len);
+        if (a.split_len == 512 * w8)  // one pass: the rows stay in registers across a strip
+            return w8 == 4   ? sym_launch(&force_sym_kernel<4, false, 3, 1>, a.n_tiles, 4, lds8, a, stream)
+                   : w8 == 2 ? sym_launch(&force_sym_kernel<2, false, 3, 1>, a.n_tiles, 2, lds8, a, stream)
+                             : sym_launch(&force_sym_kernel<1, false, 3, 1>, a.n_tiles, 1, lds8, a, stream);
         return w8 == 4   ? sym_launch(&force_sym_kernel<4, false, 3>, a.n_tiles, 4, lds8, a, stream)
                : w8 == 2 ? sym_launch(&force_sym_kernel<2, false, 3>, a.n_tiles, 2, lds8, a, stream)
                          : sym_launch(&force_sym_kernel<1, false, 3>, a.n_tiles, 1, lds8, a, stream);
@@ -1297,9 +1409,14 @@ hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
     if ((a.packed == 2 || a.packed == 3) && !a.eps_pp && a.eps2 > 0.f && a.split_len % 1024 == 0) {
         const int w8 = a.split_len % 2048 == 0 ? 4 : 2;  // whole passes of 512 rows per wave
         const size_t lds8 = sym_lds_bytes_for(w8, a.split_len);
+        if (a.packed == 3 && a.split_len == 512 * w8)  // both eight-row loops, one pass: the rows stay in registers across a strip
+            return w8 == 4 ? sym_launch(&force_sym_kernel<4, false, 2, 1>, a.n_tiles, 4, lds8, a, stream)
+                           : sym_launch(&force_sym_kernel<2, false, 2, 1>, a.n_tiles, 2, lds8, a, stream);
         if (a.packed == 3)  // the eight-row loop for arbitrary masses too (three waves per SIMD)
             return w8 == 4 ? sym_launch(&force_sym_kernel<4, false, 2>, a.n_tiles, 4, lds8, a, stream)
                            : sym_launch(&force_sym_kernel<2, false, 2>, a.n_tiles, 2, lds8, a, stream);
+        if (a.strip_len > 1)  // strips exist with 2048-body splits only: four waves
+            return sym_launch(&force_sym_kernel<4, false, 1, 2>, a.n_tiles, 4, lds8, a, stream);
         return w8 == 4 ? sym_launch(&force_sym_kernel<4, false, 1>, a.n_tiles, 4, lds8, a, stream)
                        : sym_launch(&force_sym_kernel<2, false, 1>, a.n_tiles, 2, lds8, a, stream);
     }
@@ -1355,7 +1472,7 @@ __global__ __launch_bounds__(kTile) void sym_colparts_kernel(const float3 *col_p
 // the rows of the groups a launch has finished can be summed while later tiles still run.  rowsum (already offset to the
 // first of these rows) has out_stride entries per group.
 __global__ __launch_bounds__(kTile) void sym_rowsum_kernel(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count,
-                                                           int split_len, int n_splits, int group_splits, int out_stride)
+                                                           int split_len, int n_splits, int group_splits, int out_stride, int strip_len)
 {
     // grid.y = the column groups: one (row, group) sum per lane.  A part of one row group at N = 2^20 is 131 072 rows: with
     // one lane per row walking all 257 entries the pass was bound by load latency (0.27 ms for 0.4 GB), not by HBM.
@@ -1366,13 +1483,25 @@ __global__ __launch_bounds__(kTile) void sym_rowsum_kernel(const float3 *row_par
     const int B = (row_lo + b) / split_len;
     const int c0 = g * group_splits, c1 = min(c0 + group_splits, n_splits);
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int C = c0; C < c1; ++C)
-        if (C == B || sym_rows_side(B, C, n_splits)) {
-            const float3 v = row_partials[(size_t)sym_distance(B, C, n_splits) * row_count + b];
+    // the group's column splits in ascending order, strip by strip (strip_len 1: tile by tile); the diagonal tile at its place
+    for (int C = c0; C < c1; ++C) {
+        int slot = -1;
+        if (C == B)
+            slot = 0;
+        else if (sym_rows_side(B, C, n_splits)) {
+            bool first = true;  // of its strip: the strip's sum is added once, where its first tile stands
+            for (int P = C - C % strip_len; P < C; ++P)
+                first = first && !(P != B && sym_rows_side(B, P, n_splits));
+            if (first)
+                slot = sym_row_slot(B, C, n_splits, strip_len);
+        }
+        if (slot >= 0) {
+            const float3 v = row_partials[(size_t)slot * row_count + b];
             sx += v.x;
             sy += v.y;
             sz += v.z;
         }
+    }
     rowsum[(size_t)g * out_stride + b] = make_float4(sx, sy, sz, 0.f);
 }
 
@@ -1477,13 +1606,13 @@ hipError_t launch_sym_colparts(const float3 *col_partials, float4 *colparts, int
 }
 
 hipError_t launch_sym_rowsum(const float3 *row_partials, float4 *rowsum, int row_lo, int row_count, int split_len, int n_splits,
-                             int group_splits, int out_stride, hipStream_t stream)
+                             int group_splits, int out_stride, int strip_len, hipStream_t stream)
 {
     if (row_count <= 0)
         return hipSuccess;
     const int n_groups = (n_splits + group_splits - 1) / group_splits;
     hipLaunchKernelGGL(sym_rowsum_kernel, dim3((row_count + kTile - 1) / kTile, n_groups), dim3(kTile), 0, stream, row_partials,
-                       rowsum, row_lo, row_count, split_len, n_splits, group_splits, out_stride);
+                       rowsum, row_lo, row_count, split_len, n_splits, group_splits, out_stride, strip_len);
     return hipGetLastError();
 }
 

@@ -254,6 +254,11 @@ class NBodySystem:
             self._steps_since_order += run
             k -= run
 
+    def set_strip_len(self, length: int) -> None:
+        """Pair-once mode: column splits a tile workgroup takes with the rows' sums kept in registers (``nbody_set_strip_len``;
+        0 = automatic: 4 with 2048-body splits, i.e. from N = 2^20)."""
+        check(self._lib.nbody_set_strip_len(self._ctx, int(length)), self._ctx)
+
     def set_graph_replay(self, mode: int) -> None:
         """-1: automatic (pair-once mode up to 32 768 bodies, where the replay measured faster), 0: never, 1: always."""
         check(self._lib.nbody_set_graph_replay(self._ctx, int(mode)), self._ctx)

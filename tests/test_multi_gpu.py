@@ -261,6 +261,32 @@ def test_headline_size_two_shards_on_one_gpu_equal_one_context(oracle_mod, force
     assert np.array_equal(p1[:, 3], pos[:, 3]) and np.all(v1[:, 3] == 0)
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_strips_shard_like_single_tiles(world):
+    """Round 4: with strips (2048-body splits, four column splits per tile workgroup) the blocks of four are absolute and never
+    straddle a summation group or a rank's column chunk, so 2, 4 and 8 shards with the library-owned exchange still end with the
+    bits of one context -- N = 65 536 with 2048-body splits: 32 splits, one group = one strip length, the tightest case."""
+    import n_body_problem_amd as nb
+    from n_body_problem_amd.multi import MultiGpuSystem
+    n, steps = 65536, 3
+    pos, vel = nb.plummer(n, seed=41)
+    pos[: n // 5, 3] *= 3.0                      # two species: strips of one mass and mixed ones
+    with nb.NBodySystem(n, split_len=2048) as s:
+        s.set_force_mode("pair_once")
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        s.step_n(steps, DT, EPS)
+        want_p, want_v = s.download()
+    for exchange in ("allgather", "ring"):
+        with MultiGpuSystem(n, devices=[0] * world, force_mode="pair_once", exchange=exchange, transport="peer_copy",
+                            split_len=2048) as m:
+            m.set_state(pos, vel)
+            m.step_n(steps, DT, EPS)
+            p, v = m.download()
+            assert m.replicas_identical()
+        assert np.array_equal(p, want_p) and np.array_equal(v, want_v), (world, exchange)
+
+
 @pytest.mark.parametrize("integrator", ["kick_drift", "kdk"])
 def test_config5_shape_thousand_steps_one_context_and_two_shards(integrator):
     """BASELINE configs[4] in shape, at a size the GPU suite can afford: a long run (1000 steps) of a Plummer sphere in the

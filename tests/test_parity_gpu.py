@@ -677,6 +677,66 @@ def test_summation_parts_change_no_bit(nb, integrator):
     assert np.array_equal(p, out[1][0]) and np.array_equal(v, out[1][1])
 
 
+@pytest.mark.parametrize("n", [65536, 131072])
+def test_strips_keep_the_rows_sums_in_registers_and_the_results(nb, oracle_mod, n):
+    """Round 4, strips: with 2048-body splits and a split count that is a multiple of 32 a tile workgroup takes four consecutive
+    column splits of its row split and keeps the rows' sums in registers across them -- a quarter of the row-side partial sums.
+    Against the fp64 oracle (sampled rows), against single tiles (nbody_set_strip_len(1): equal to rounding, not bit for bit:
+    one chain per row over a strip's columns instead of a sum of four), Newton's third law; every loop that serves strips --
+    equal masses (S8), arbitrary masses (S9), per-particle softening with either (S12, S10), eps = 0 and the four-row /
+    compiler-scheduled kernels (each tile's row sums added to the strip's in memory); 1, 2, 4 and 8 summation parts the same
+    bits; fewer bytes of partial sums held; a column range that cuts a strip refused."""
+    pos, vel = nb.plummer(n, seed=n + 7)
+    rng = np.random.default_rng(n)
+    eps_pp = rng.uniform(0.0, 0.02, n).astype(np.float32)
+    rows = [(0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n)]
+
+    def accel(strip, masses=None, eps=1e-3, pps=None, rpl=0, parts=0):
+        p = pos.copy()
+        if masses is not None:
+            p[:, 3] = masses
+        with nb.NBodySystem(n, split_len=2048) as s:
+            s.set_force_mode("pair_once")
+            s.set_strip_len(strip)
+            s.set_rows_per_lane(rpl)
+            s.set_summation_parts(parts)
+            if pps is not None:
+                s.set_particle_softening(pps)
+            s.setParticlesPosition(p)
+            s.setParticlesVelocity(np.zeros_like(p))
+            s.step(1.0, eps)
+            return s.download()[1][:, :3].astype(np.float64), s.partial_sum_bytes()
+
+    random_masses = (pos[:, 3] * rng.uniform(0.5, 2.0, n)).astype(np.float32)
+    cases = {"equal masses": {}, "arbitrary masses": {"masses": random_masses}, "pps, equal masses": {"pps": eps_pp},
+             "pps, arbitrary masses": {"pps": eps_pp, "masses": random_masses}, "eps = 0": {"eps": 0.0},
+             "four-row loops": {"rpl": 4}, "pps, eps = 0": {"pps": eps_pp, "eps": 0.0}}
+    for name, kw in cases.items():
+        a4, held4 = accel(0, **kw)
+        a1, held1 = accel(1, **kw)
+        p = pos.copy()
+        if "masses" in kw:
+            p[:, 3] = kw["masses"]
+        for lo, hi in rows:
+            want = (oracle_mod.accel_f64_pps(p, kw["pps"], kw.get("eps", 1e-3), i0=lo, i1=hi) if "pps" in kw
+                    else oracle_mod.accel_f64(p, i0=lo, i1=hi, eps=kw.get("eps", 1e-3)))
+            assert np.linalg.norm(a4[lo:hi] - want) / np.linalg.norm(want) < TOL, name
+        assert np.linalg.norm(a4 - a1) / np.linalg.norm(a1) < 1e-6 and not np.array_equal(a4, a1), name
+        m = p[:, 3].astype(np.float64)
+        net = (m[:, None] * a4).sum(0)
+        assert np.all(np.abs(net) < 1e-5 * (m[:, None] * np.abs(a4)).sum(0)), name
+        assert held4 < 0.7 * held1, (name, held4, held1)          # rows: a quarter; columns: what they were
+    base, _ = accel(0)
+    for parts in (1, 2, 4, 8):
+        assert np.array_equal(accel(0, parts=parts)[0], base), parts
+    with nb.NBodySystem(n, split_len=2048) as s:
+        s.set_force_mode("pair_once")
+        s.setParticlesPosition(pos)
+        s.setParticlesVelocity(vel)
+        with pytest.raises(nb.NBodyError):
+            s.forces(0, 2 * 2048, 1e-3)                              # two of a strip's four column splits
+
+
 def test_summation_parts_api(nb):
     """Changing the number of parts between steps is allowed (the plans are rebuilt); a column-range call after an all-columns
     call in several parts is refused (the earlier parts are already summed); bad values are refused."""
