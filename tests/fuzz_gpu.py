@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-os.environ.setdefault("NBODY_SYM_PARTS_MIN_TILES", "0")    # summation parts (several tile launches) at every size
+# an explicit nbody_set_summation_parts is honoured at every size (round 4: no environment switch in the library any more)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import n_body_problem_amd as nb  # noqa: E402
