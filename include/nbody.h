@@ -298,8 +298,10 @@ int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
  * added in row groups (NBODY_SYM_GROUPS), so the tiles can be launched in parts of whole groups, and while one part's
  * tiles run an auxiliary stream already forms the sums of the part before it: only the last part's share of the
  * summation and the combination stay behind the force pass.  The result does not change by a bit (the association is by
- * groups either way).  parts = 1: one launch, then the whole summation.  2: every group but the last, then the last (one
- * extra launch tail; the partial-sum arrays hold the whole pass: n^2 / split_len 12-byte entries, 6.4 GB at N = 2^20).
+ * groups either way).  parts = 1: one launch, then the whole summation.  2: every group but the last, then the last -- the
+ * last part's tiles on a stream of the lowest priority that does not wait for the first part's, so the dispatcher fills the
+ * first launch's tail with the second's workgroups (measured 0.2-0.3 % faster than one launch at N = 2^20; the two launches
+ * overlap, so per-launch timings stop adding up to the pass); the partial-sum arrays hold the whole pass.
  * 4, 8: parts whose arrays live in two slots used in turn, for one launch tail (0.2-0.5 ms) per extra part (measured at
  * N = 2^20 with 1024-body splits: 8 parts cost ~1 % of the step against 1).  8: equal parts, a quarter of the pass held
  * (26 GB at N = 2^22).  4: 3 + 3 + 1 + 1 of the 8 groups -- what stays behind the force pass is the LAST part's summation,

@@ -80,6 +80,7 @@ struct nbody_ctx {
     } graph_key;
     int graph_replay = -1;  // -1: automatic (systems of at most kGraphAutoBodies bodies), 0: off, 1: on
     hipStream_t aux_stream = nullptr;  // pair-once mode: the diagonal-tile launch runs here, beside the tile launch
+    hipStream_t tail_stream = nullptr; // pair-once mode, two summation parts: the LAST part's tiles, lowest priority, beside the first's
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_graph_in = nullptr, ev_graph_out = nullptr;
     hipEvent_t ev_flags = nullptr;  // the step's equal-mass flags have been written (a later force call may run on another stream)
     bool flags_valid = false;       // split_mass holds the flags of the positions of this step (launch_split_mass has run since the
@@ -498,6 +499,7 @@ int nbody_destroy(nbody_ctx *c)
     if (c->ev_graph_in) (void)hipEventDestroy(c->ev_graph_in);
     if (c->ev_graph_out) (void)hipEventDestroy(c->ev_graph_out);
     if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
+    if (c->tail_stream) (void)hipStreamDestroy(c->tail_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1332,9 +1334,20 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         for (int p = 0; p < std::min(K, 2); ++p)
             if (int rc = diag_launch(p))
                 return rc;
+        // Two parts (7 groups + 1): the last part's tiles go on a stream of the LOWEST priority that does not wait for the first
+        // part's -- the dispatcher serves the first part's workgroups while it has any and fills their tail with the second
+        // part's, so the extra launch costs no tail, and the first part's summation (7/8 of it) runs beside the second part's
+        // tiles instead of behind the pass.
+        if (K == 2 && !c->tail_stream) {
+            int least = 0, greatest = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, least));
+        }
         for (int p = 0; p < K; ++p) {
             const nbody_ctx::SymPart &part = plan.parts[(size_t)p];
-            hipStream_t ts = c->stream;
+            hipStream_t ts = K == 2 && p == 1 ? c->tail_stream : c->stream;
+            if (ts != c->stream)
+                HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_fork, 0));  // the positions and the equal-mass flags are in place
             if (K > 2 && p >= 2)
                 HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_red[(size_t)p - 2], 0));
             part_args(part);
@@ -1342,8 +1355,13 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 TimedLaunch t(c, &c->ev_force, &c->force_ms, &c->force_launches, ts, true);  // the dominant kernel alone
                 HIP_TRY(c, launch_forces_symmetric(sa, ts));
             }
-            if (p == K - 1)
-                break;  // the last part's sums are formed on the context's stream
+            if (p == K - 1) {
+                if (ts != c->stream) {  // the last part's sums are formed on the context's stream
+                    HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], ts));
+                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_tiles[(size_t)p], 0));
+                }
+                break;
+            }
             HIP_TRY(c, hipEventRecord(c->ev_tiles[(size_t)p], ts));
             HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_tiles[(size_t)p], 0));
             {

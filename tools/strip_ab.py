@@ -15,7 +15,7 @@ def main():
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     pos, vel = nb.plummer(n, seed=nb.CONFIG_SEED[3])
     systems = []
-    for strip, parts in ((1, 0), (4, 0), (4, 4), (2, 0)):
+    for strip, parts in ((1, 0), (4, 0), (4, 2), (4, 1)):
         s = nb.NBodySystem(n, split_len=nb.pair_once_split_len(n), body_order="morton")
         s.set_force_mode("pair_once")
         s.set_strip_len(strip)
