@@ -97,7 +97,8 @@ def reference_size_leg(nb):
     pos, vel = datasets.read_tipsy(path)
     n = pos.shape[0]
     ppos, pvel = nb.pad_reference_style(pos, vel)            # the reference's 20225-body buffers
-    s = nb.NBodySystem(ppos.shape[0])
+    s = nb.initialize(ppos.shape[0], force_mode="auto")     # nbody_create_auto: what INTEGRATION.md section 2 patches in
+    mode, split_len = s.force_mode, s.split_len
     s.setParticlesPosition(ppos)
     s.setParticlesVelocity(pvel)
     s.step_n(20, nb.TIME_TICK, nb.SOFTENING_VERSION3)
@@ -109,7 +110,7 @@ def reference_size_leg(nb):
     ms = 1e3 * (time.perf_counter() - t0) / k
     s.close()
     return {"input": "tests/golden/galaxy_20K.bin (the reference's data/galaxy_20K.bin)", "n_bodies": n,
-            "n_padded": int(ppos.shape[0]), "ms_per_step": ms, "interactions_per_s": float(n) * n / (ms * 1e-3),
+            "n_padded": int(ppos.shape[0]), "force_mode": mode, "split_len": split_len, "ms_per_step": ms, "interactions_per_s": float(n) * n / (ms * 1e-3),
             "reference_ms_per_step": 1.6, "reference_hardware": "RTX 4090 (source comment kernel.cu:73, N inferred)",
             "speedup_vs_reference_comment": 1.6 / ms}
 

@@ -68,8 +68,8 @@ int nbody_create_shard(nbody_ctx **out, int device, int64_t n_total, int64_t row
                        int64_t split_len);
 /* nbody_create_auto: nbody_create with the force mode that is faster at this body count already selected, and the split
  * length that mode wants (what nbody_set_force_mode(ctx, NBODY_FORCE_AUTO) does to an existing context): the pair-once
- * kernels from NBODY_PAIR_ONCE_MIN_BODIES bodies on, the one-sided ones below.  The one call a caller of the reference's
- * bracket (kernel.cu:1225-1242) needs to land on the fast kernels at every N. */
+ * kernels from NBODY_PAIR_ONCE_MIN_BODIES bodies on (since round 4: at every size), the one-sided ones below.  The one call
+ * a caller of the reference's bracket (kernel.cu:1225-1242) needs to land on the fast kernels at every N. */
 int nbody_create_auto(nbody_ctx **out, int device, int64_t n_total);
 int nbody_destroy(nbody_ctx *ctx);
 const char *nbody_last_error(const nbody_ctx *ctx); /* ctx == NULL: last error of a failed create */
@@ -153,9 +153,8 @@ int nbody_step(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw
 int nbody_step_async(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, const float *d_masses,
                      float dt, float softening);
 int nbody_step_n(nbody_ctx *ctx, int k, float dt, float softening); /* k steps on the owned buffers, one sync */
-/* The same on caller-owned device buffers.  Where the loop is launch-bound -- measured: the pair-once mode (seven launches
- * on two streams per step) up to 32 768 bodies; the three launches of a one-sided step are faster enqueued eagerly at every
- * size -- ONE step is captured from the stream into a HIP graph after an eager first step and replayed k - 1 times: the
+/* The same on caller-owned device buffers.  Where the loop is launch-bound -- measured: the pair-once mode up to 32 768
+ * bodies; the launches of a one-sided step are faster enqueued eagerly at every size -- ONE step is captured from the stream into a HIP graph after an eager first step and replayed k - 1 times: the
  * same kernels, arguments and order, hence the same bits.  nbody_set_graph_replay: -1 automatic (that rule), 0 never,
  * 1 always. */
 int nbody_step_n_on(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, int k, float dt, float softening);
@@ -233,11 +232,14 @@ int nbody_timing_read(nbody_ctx *ctx, double *force_ms, int64_t *force_launches,
  *     nbody_update / nbody_kdk_*                (adds row-side and column-side sums in the fixed order)
  * A context that owns all rows may skip nbody_sym_reduce (nbody_update / nbody_step run it). */
 /* NBODY_FORCE_AUTO (nbody_set_force_mode only; a context that owns every row, nothing pending): the pair-once mode from
- * NBODY_PAIR_ONCE_MIN_BODIES bodies on -- where it delivers more interactions per second (profiles/r03_mode_crossover.txt:
- * N = 32 768: 0.229 against 0.251 ms per step, 65 536: 0.71 against 0.94, 2^20: 150 against 229) -- the one-sided mode below,
- * where the pair-once grid is too coarse to fill the chip (N = 24 576: 0.164 against 0.148 ms, 20 225: 0.18 against 0.12), and the context's split length is changed to the one that mode wants
- * (nbody_pair_once_split_len / nbody_default_split_len).  nbody_force_mode reads the mode in use. */
-#define NBODY_PAIR_ONCE_MIN_BODIES 32768
+ * NBODY_PAIR_ONCE_MIN_BODIES bodies on -- where it delivers more interactions per second -- the one-sided mode below, and the
+ * context's split length is changed to the one that mode wants (nbody_pair_once_split_len / nbody_default_split_len).
+ * Rounds 1-3: 32 768 (below it one wave per 256 x 256 tile left the grid too coarse: 0.157 against 0.122 ms per step at the
+ * reference's 20 225 bodies).  Round 4: 0 -- with 256-body splits a tile is served by four waves, a 64-column group each, the
+ * diagonal tiles in the same launch, and the pair-once step is the faster one at every size measured, 256 bodies to 2^22
+ * (profiles/r04_pair_once_small_n.txt: 20 225 bodies 0.087 against 0.109 ms, 4096: 0.019 against 0.029, 32 768: 0.195 against
+ * 0.258, 2^20: 150 against 229).  nbody_force_mode reads the mode in use. */
+#define NBODY_PAIR_ONCE_MIN_BODIES 0
 enum { NBODY_FORCE_ONE_SIDED = 0, NBODY_FORCE_SYMMETRIC = 1, NBODY_FORCE_AUTO = 2 };
 int nbody_force_mode(const nbody_ctx *ctx);
 /* The split length to create a pair-once context with.  A function of n_total ONLY (split boundaries define the

@@ -37,7 +37,7 @@ public:
         n_ = numBodies;
     }
     // initialize(numBodies) with the faster force mode for this body count already selected (nbody_create_auto): the
-    // pair-once kernels from NBODY_PAIR_ONCE_MIN_BODIES bodies on, the one-sided ones below.
+    // pair-once kernels from NBODY_PAIR_ONCE_MIN_BODIES bodies on (round 4: at every size), the one-sided ones below.
     void initializeAuto(std::int64_t numBodies, int device = 0)
     {
         nbody_destroy(ctx_);

@@ -185,8 +185,9 @@ int64_t nbody_default_split_len(int64_t n_total)
     // 5 x 320 = 1600 columns per SIMD instead of 7 x 256 = 1792; measured 100.4 against 108.3 us per force pass, 0.108 against
     // 0.116 ms per step (profiles/r04_small_n_split.txt).  256 stays wherever nothing is strictly better (shorter splits were
     // tried: the partial sums they add cost the update more than the pass gains).  Still a function of n_total only.
+    constexpr int64_t kOneWaveKernelBodies = 32768;  // below it a one-sided workgroup is one wave (force_kernel_r4pk_w1)
     const int64_t rb = (n_total + kTile - 1) / kTile;
-    if (n_total < NBODY_PAIR_ONCE_MIN_BODIES && rb * rb > 2048) {
+    if (n_total < kOneWaveKernelBodies && rb * rb > 2048) {
         auto rounds = [&](int64_t L) { return ((n_total + L - 1) / L * rb + 1023) / 1024; };
         int64_t best = kTile;
         for (int64_t L = kTile + 64; L <= 2 * kTile; L += 64)
@@ -1297,6 +1298,8 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         sa.packed = c->rows_per_lane == 4 ? 1 : c->rows_per_lane == 2 ? 2 : c->rows_per_lane == 1 ? 0 : 3;
         if (sa.packed >= 2 && !c->equal_mass_path)
             sa.packed = 3;  // no tile can take the equal-mass loop
+        sa.equal_mass_path = c->equal_mass_path ? 1 : 0;
+        const bool quarter = sym_quarter_tiles(L, sa.eps2, sa.eps_pp, sa.packed);  // small systems: no flags, no diagonal launch
         auto part_args = [&](const nbody_ctx::SymPart &p) {
             sa.row_partials = reinterpret_cast<float3 *>(c->partials) + p.row_off;
             sa.col_partials = c->col_partials + p.col_off;
@@ -1311,7 +1314,9 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         HIP_TRY(c, hipSetDevice(c->device));
         // the equal-mass flags once per step, by its first force call: a later call for other columns (the complement launch on
         // a second stream, the ring's chunks) would rewrite the same values under the kernels that read them
-        if (!c->flags_valid) {
+        if (quarter) {
+            // the quarter-tile kernel reads the masses itself
+        } else if (!c->flags_valid) {
             HIP_TRY(c, launch_split_mass(sa.pos, c->split_mass, sa.n_total, L, c->equal_mass_path, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev_flags, c->stream));
             c->flags_valid = true;

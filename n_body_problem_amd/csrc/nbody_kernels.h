@@ -93,10 +93,18 @@ struct SymArgs {
     float eps2;
     const float *eps_pp;   // optional per-particle softening lengths (n_total floats): eps_ij^2 = eps2 + eps_i^2 + eps_j^2
     const float *split_mass;  // [n_splits]: the one mass of a split's bodies, or NaN (launch_split_mass)
+    int equal_mass_path;      // 0: no tile takes the equal-mass loops (nbody_set_equal_mass_path; the quarter-tile kernel decides itself)
     int packed;               // 0: one-column loops; 1: packed two-columns-per-step loops, four rows per lane; 2: and eight rows
                               // per lane on equal-mass tiles of splits of whole 1024 bodies; 3 (default): eight rows per lane
                               // on every tile of such splits (one kernel, allocated for three waves per SIMD)
 };
+// Small systems (256-body splits, the packed loops; not per-particle softening with eps = 0, where a pair may meet at r^2 = 0
+// unguarded): the tiles AND the diagonal tiles are served by force_sym_quarter_kernel in ONE launch (launch_forces_symmetric),
+// which needs no split_mass flags.
+inline bool sym_quarter_tiles(int split_len, float eps2, const float *eps_pp, int packed)
+{
+    return split_len == 256 && packed >= 2 && !(eps_pp && !(eps2 > 0.f));
+}
 // split_mass[s] for every split of the body set, from the masses now in pos (O(N); see split_mass_kernel)
 hipError_t launch_split_mass(const float4 *pos, float *split_mass, int n_total, int split_len, bool enabled, hipStream_t stream);
 hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);       // the tiles (R != C)

@@ -416,7 +416,7 @@ class NBodySystem:
                 "name": name.value.decode()}
 
 
-PAIR_ONCE_MIN_BODIES = 32768  # below it the pair-once grid is too coarse to fill the chip
+PAIR_ONCE_MIN_BODIES = 0  # NBODY_PAIR_ONCE_MIN_BODIES: since round 4 the pair-once step is the faster one at every size
 
 
 def initialize(num_bodies: int, device: int = 0, force_mode: str = "one_sided", body_order: str = "given") -> NBodySystem:

@@ -203,12 +203,12 @@ def test_config5_dry_run_two_ranks_on_one_gpu_with_snapshots(tmp_path):
 
 
 def test_cli_auto_flag_is_the_librarys_choice_of_force_mode(tmp_path):
-    """--auto = nbody_create_auto (one context) / NBODY_FORCE_AUTO in nbody_multi_config (--devices): the one-sided kernels
-    at the reference's own size, the pair-once kernels from 32 768 bodies on -- the same bits as initialize(force_mode="auto")."""
+    """--auto = nbody_create_auto (one context) / NBODY_FORCE_AUTO in nbody_multi_config (--devices): the pair-once
+    kernels at every size since round 4 (NBODY_PAIR_ONCE_MIN_BODIES = 0) -- the same bits as initialize(force_mode="auto")."""
     import n_body_problem_amd as nb
     from n_body_problem_amd import datasets as ds
     from n_body_problem_amd.multi import MultiGpuSystem
-    for n, want in ((6000, "one-sided"), (32768, "pair-once")):
+    for n, want in ((6000, "pair-once"), (32768, "pair-once")):
         pos, vel = nb.plummer(n, seed=94)
         start = str(tmp_path / f"start_{n}.nbs")
         ds.save_snapshot(start, pos, vel, step=0, time=0.0)

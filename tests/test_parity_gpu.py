@@ -1239,7 +1239,7 @@ def test_c_abi_auto_mode_lands_on_the_fast_kernels(nb, oracle_mod):
     one call gives the force mode -- and the split length it needs -- that initialize(force_mode="auto") gives Python."""
     from n_body_problem_amd import _lib
     lib = _lib.load()
-    for n, want_mode in ((20225, 0), (32767, 0), (32768, 1), (1 << 18, 1)):
+    for n, want_mode in ((1000, 1), (20225, 1), (32768, 1), (1 << 18, 1)):   # round 4: the pair-once kernels at every size
         pos, vel = nb.plummer(n, seed=18)
         want_len = nb.pair_once_split_len(n) if want_mode else nb.default_split_len(n)
         results = []
