@@ -90,10 +90,11 @@ def test_linearity_in_mass_and_translation(nb, mode):
 
 
 def test_initialize_picks_the_force_mode_by_size(nb, oracle_mod):
-    for n, want_len in ((5000, nb.default_split_len(5000)), (65536, nb.pair_once_split_len(65536))):
+    # round 4: the pair-once kernels are the faster ones at every size (NBODY_PAIR_ONCE_MIN_BODIES = 0)
+    for n, want_len in ((700, 256), (5000, nb.pair_once_split_len(5000)), (65536, nb.pair_once_split_len(65536))):
         pos, vel = nb.plummer(n, seed=3)
         with nb.initialize(n, force_mode="auto") as s:
-            assert s.split_len == want_len
+            assert s.split_len == want_len and s.force_mode == "pair_once"
             s.setParticlesPosition(pos)
             s.setParticlesVelocity(vel)
             s.step(1e-3, 1e-3)
@@ -901,6 +902,83 @@ def test_symmetric_mode_matches_oracle_and_one_sided(nb, oracle_mod, n, split_le
     assert np.array_equal(p1, p2) and np.array_equal(v1, v2)                           # bit-reproducible
     pr, vr = sym_run(nb, pos, vel, 1e-3, 1e-3, 3, "one_sided", split_len)
     assert rel_state_error(p1, pr) < 1e-6 and rel_state_error(v1, vr) < 1e-6
+
+
+@pytest.mark.parametrize("n", [200, 256, 1000, 5000, 20225])
+def test_small_systems_tile_by_four_waves(nb, oracle_mod, n):
+    """Round 4, 256-body splits (every system below 65 536 bodies): a tile is served by four waves, one 64-column group each, the
+    diagonal tiles by the same kernel in the same launch (force_sym_quarter_kernel).  Each WAVE decides whether its rows and its
+    64 columns carry one mass: body sets whose species change inside a split, inside a 64-column group and on their boundaries;
+    massless bodies; coincident bodies; eps = 0 (the guarded loop) and per-particle softening (their own loops); all against the
+    fp64 truth and the one-sided kernels, the equal-mass path on and off, and two shards = one context, bit for bit."""
+    rng = np.random.default_rng(n)
+    pos, vel = nb.plummer(n, seed=500 + n)
+    cases = {"equal": pos.copy()}
+    sp = pos.copy()
+    for cut, m in zip(sorted(rng.integers(0, n + 1, 4)), (3.0, 0.25, 7.0, 0.5)):      # species in index order, boundaries anywhere
+        sp[cut:, 3] = pos[cut:, 3] * m
+    cases["species"] = sp
+    rnd = pos.copy()
+    rnd[:, 3] = rng.uniform(0.0, 2.0, n).astype(np.float32) / n
+    rnd[rng.random(n) < 0.05, 3] = 0.0                                               # massless bodies
+    k = rng.integers(0, n, size=max(1, n // 40))
+    rnd[k, :3] = rnd[(k + 1) % n, :3]                                                # coincident bodies
+    cases["random"] = rnd
+    eps_pp = rng.uniform(0.0, 0.05, n).astype(np.float32)
+    for name, state in cases.items():
+        for eps, pps in ((1e-2, False), (0.0, False), (1e-2, True)):
+            if eps == 0.0 and name != "random":
+                continue
+            acc = {}
+            for mode, on in (("pair_once", True), ("pair_once", False), ("one_sided", True)):
+                with nb.NBodySystem(n, split_len=256) as s:
+                    s.set_force_mode(mode)
+                    s.set_equal_mass_path(on)
+                    if pps:
+                        s.set_particle_softening(eps_pp)
+                    s.setParticlesPosition(state)
+                    s.setParticlesVelocity(np.zeros_like(vel))
+                    s.step(1.0, eps)
+                    acc[(mode, on)] = s.download()[1][:, :3].astype(np.float64)
+            a64 = oracle_mod.accel_f64_pps(state, eps_pp, eps) if pps else oracle_mod.accel_f64(state, eps=eps)
+            scale = np.linalg.norm(a64)
+            err = {key: np.linalg.norm(a - a64) / scale for key, a in acc.items()}
+            assert np.isfinite(acc[("pair_once", True)]).all(), (name, eps, pps)
+            if eps > 0:
+                assert max(err.values()) < TOL, (name, eps, pps, err)
+            assert err[("pair_once", True)] <= max(1e-6, 3 * err[("one_sided", True)]), (name, eps, pps, err)
+            assert np.linalg.norm(acc[("pair_once", True)] - acc[("pair_once", False)]) / scale < 1e-6
+            m = state[:, 3:4].astype(np.float64)                                     # Newton's third law, pair by pair
+            a = acc[("pair_once", True)]
+            assert np.all(np.abs((m * a).sum(0)) <= 1e-6 * (m * np.abs(a)).sum(0) + 1e-30), (name, eps, pps)
+    # steps are bit-reproducible, the graph replay included, and two row shards end with one context's bits
+    state = cases["species"]
+    runs = []
+    for graph in (0, 1):
+        with nb.NBodySystem(n, split_len=256) as s:
+            s.set_force_mode("pair_once")
+            s.set_graph_replay(graph)
+            s.setParticlesPosition(state)
+            s.setParticlesVelocity(vel)
+            s.step_n(5, 1e-3, 1e-2)
+            runs.append(s.download())
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    if n >= 4096:
+        from n_body_problem_amd.multi import MultiGpuSystem
+        with MultiGpuSystem(n, devices=[0, 0], force_mode="pair_once", transport="peer_copy", split_len=256) as m:
+            m.set_state(state, vel)
+            m.step_n(5, 1e-3, 1e-2)
+            got = m.download()
+            n_padded = m.n_padded
+        pp, vv = np.zeros((n_padded, 4), np.float32), np.zeros((n_padded, 4), np.float32)
+        pp[:n], vv[:n] = state, vel
+        with nb.NBodySystem(n_padded, split_len=256) as s:
+            s.set_force_mode("pair_once")
+            s.setParticlesPosition(pp)
+            s.setParticlesVelocity(vv)
+            s.step_n(5, 1e-3, 1e-2)
+            want = s.download()
+        assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n])
 
 
 def test_symmetric_mode_row_shards_with_a_manual_exchange(nb):
