@@ -126,7 +126,10 @@ def executed_pairs(mode, n, split_len, rows_here):
     if mode == "one_sided":
         return rows_here * n
     S = -(-n // split_len)
-    return S * (S - 1) / 2 * split_len * split_len * rows_here / n
+    tiles = S * (S - 1) / 2
+    if split_len == 256:   # small systems: the tile launch serves the diagonal tiles too, as full squares (force_sym_quarter_kernel)
+        tiles += S
+    return tiles * split_len * split_len * rows_here / n
 
 
 def roofline(mode, n, split_len, rows_here, steps, tm, equal_mass=True):

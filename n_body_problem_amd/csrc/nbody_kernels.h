@@ -85,7 +85,8 @@ struct SymArgs {
     const int4 *tiles;     // n_tiles strips {R, first C, count, slot}: R an own split, C ... C + count - 1 its column splits
     int n_tiles;
     int strip_len;         // K
-    const int2 *diag_tiles;  // n_diag pairs (B, B), own splits: every pair inside the split once, both sides
+    const int2 *diag_tiles;  // n_diag pairs (B, B), own splits: every pair inside the split once, both sides (the quarter-tile kernel
+                             // of small systems: every ordered pair, row side only -- the same sums, P_row[0][b])
     int n_diag;
     int n_total;
     int split_len;         // 256 <= split_len <= 4096, multiple of 256
@@ -107,8 +108,8 @@ inline bool sym_quarter_tiles(int split_len, float eps2, const float *eps_pp, in
 }
 // split_mass[s] for every split of the body set, from the masses now in pos (O(N); see split_mass_kernel)
 hipError_t launch_split_mass(const float4 *pos, float *split_mass, int n_total, int split_len, bool enabled, hipStream_t stream);
-hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);       // the tiles (R != C)
-hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream);  // the diagonal tiles
+hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream);       // the tiles (R != C); sym_quarter_tiles(): and the diagonal tiles
+hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream);  // the diagonal tiles (sym_quarter_tiles(): nothing left to do)
 size_t symmetric_lds_bytes(int split_len);
 
 // colparts[g][c] = sum over the own splits R of group g (ascending, where the tile (R, C(c)) exists) of P_col[R][c],
