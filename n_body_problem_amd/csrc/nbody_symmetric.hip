@@ -1626,6 +1626,11 @@ hipError_t launch_forces_symmetric_diag(const SymArgs &a, hipStream_t stream)
 {
     if (sym_quarter_tiles(a.split_len, a.eps2, a.eps_pp, a.packed))
         return hipSuccess;  // served by the tile launch
+    // A diagonal workgroup must fit where a tile workgroup leaves: beside the two-wave tile kernels of 1024-body splits
+    // (three waves of ~165 registers per SIMD) a four-wave diagonal workgroup found room only in the launch's tail -- at N = 131 072
+    // the diagonal launch ended 85 us after the tiles and was the step's critical path (profiles/r04_diagonal_tiles.txt).
+    if (a.split_len == 1024)
+        return sym_launch_diag<2>(a, sym_lds_bytes_for(2, a.split_len), stream);
     const size_t lds = symmetric_lds_bytes(a.split_len);
     switch (sym_waves(a.split_len)) {
     case 4: return sym_launch_diag<4>(a, lds, stream);
