@@ -99,11 +99,13 @@ struct SymArgs {
                               // per lane on equal-mass tiles of splits of whole 1024 bodies; 3 (default): eight rows per lane
                               // on every tile of such splits (one kernel, allocated for three waves per SIMD)
 };
-// Small systems (256-body splits, the packed loops; not per-particle softening with eps = 0, where a pair may meet at r^2 = 0
-// unguarded): the tiles AND the diagonal tiles are served by force_sym_quarter_kernel in ONE launch (launch_forces_symmetric),
+// Small systems (256- and 512-body splits, the packed loops; not per-particle softening with eps = 0, where a pair may meet at r^2 = 0
+// unguarded, and not per-particle softening at all with 512-body splits): the tiles AND the diagonal tiles are served by force_sym_quarter_kernel in ONE launch (launch_forces_symmetric),
 // which needs no split_mass flags.
 inline bool sym_quarter_tiles(int split_len, float eps2, const float *eps_pp, int packed)
 {
+    if (split_len == 512)  // eight waves per tile; per-particle softening keeps the eight-row loops (S10 / S12) of force_sym_kernel there
+        return packed >= 2 && !eps_pp;
     return split_len == 256 && packed >= 2 && !(eps_pp && !(eps2 > 0.f));
 }
 // split_mass[s] for every split of the body set, from the masses now in pos (O(N); see split_mass_kernel)

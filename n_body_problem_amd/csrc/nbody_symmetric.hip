@@ -1145,17 +1145,22 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
 // everything else about the sums.  The DIAGONAL tiles go through the same loop as full squares -- every ordered pair inside the
 // split, the self pair contributing exactly 0 (dx = 0 against a finite inv3; with eps = 0 through the guard) -- and keep the row side only: twice the
 // pair evaluations of a triangle on 80 of 3240 tiles, at the hand-scheduled rate, in the same launch (workgroups >= n_tiles).
-// LOOP 0: eps > 0 (S2_GROUP_LOOP where the wave's rows carry one mass and its 64 columns one mass, else S3_GROUP_LOOP);
+// LOOP 0: eps > 0 (S2_GROUP_LOOP where the wave's rows carry one mass and its columns one mass, else S3_GROUP_LOOP);
 // 1: per-particle softening with eps > 0 (S11_GROUP_LOOP); 2: eps = 0 (the guarded one-column loop: a zero-distance pair -- the self
 // pair of a diagonal tile among them -- contributes exactly 0).
-template <int LOOP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void force_sym_quarter_kernel(SymArgs a)
+// NH = 2: 512-body splits (65 536 <= N < 131 072) by EIGHT waves -- wave (h, q) holds the 256 rows of half h of the row split and
+// meets quarter q of the column split, two 64-column groups one after the other; a row's sum is the sums of the four waves of
+// its half in wave order, a column's sum the sum of half 0's wave and half 1's, in that order, through LDS.
+template <int LOOP, int NH>
+__global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(NH == 1 ? 5 : 4))) void force_sym_quarter_kernel(SymArgs a)
 {
-    constexpr int L = 256;
-    __shared__ __attribute__((aligned(1024))) float stage_all[4 * kSymStageFloatsPerWave];
-    __shared__ float estage_all[LOOP == 1 ? 4 * 128 : 1];
-    __shared__ float xch[4][3][L];  // the waves' row sums
+    constexpr int L = 256 * NH, NW = 4 * NH, GPW = NH;  // split length, waves, 64-column groups per wave
+    __shared__ __attribute__((aligned(1024))) float stage_all[NW * kSymStageFloatsPerWave];
+    __shared__ float estage_all[LOOP == 1 ? NW * 128 : 1];
+    __shared__ float xch[NW][3][256];                           // the waves' row sums
+    __shared__ float colx[NH == 2 ? 4 : 1][GPW][3][64];         // NH = 2: half 1's column sums on their way to half 0's wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = NH == 1 ? 0 : wave >> 2, q = wave & 3;
     const bool diag = (int)blockIdx.x >= a.n_tiles;
     int R, C, slot;
     if (diag) {
@@ -1165,7 +1170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         const int4 t = a.tiles[blockIdx.x];
         R = t.x, C = t.y, slot = t.w;
     }
-    const int rowbase = R * L, colbase = C * L;
+    const int rowbase = R * L + h * 256, colbase = C * L;
     const int row_hi = min(a.row_lo + a.row_count, a.n_total);
     const int S = (a.n_total + L - 1) / L;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1173,7 +1178,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
     nb_f4 row[kSymRows];
     float er[kSymRows];  // LOOP 1: eps^2 + eps_i^2 of the rows
     bool same = true;
-    const unsigned mref = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.pos[rowbase].w));  // rowbase < row_hi
+    // the one mass of the wave's rows and of its columns, if there is one: missing bodies count as zero-mass ones (split_mass_kernel)
+    const unsigned mref = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, rowbase < row_hi ? a.pos[rowbase].w : 0.f));
 #pragma unroll
     for (int k = 0; k < kSymRows; ++k) {
         const int r = rowbase + k * 64 + lane;
@@ -1188,129 +1194,156 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         er[k] = __builtin_fmaf(e, e, a.eps2);
         same &= __builtin_bit_cast(unsigned, p.w) == mref;
     }
-    const int gc = colbase + wave * 64 + lane;
-    float4 c = zero4;
-    float ec = 0.f;
-    if (gc < a.n_total) {
-        c = a.pos[gc];
-        if (LOOP == 1)
-            ec = a.eps_pp[gc];
+    float4 c[GPW];
+    float ec[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        const int gc = colbase + (q * GPW + i) * 64 + lane;
+        c[i] = zero4;
+        ec[i] = 0.f;
+        if (gc < a.n_total) {
+            c[i] = a.pos[gc];
+            if (LOOP == 1)
+                ec[i] = a.eps_pp[gc];
+        }
     }
-    const unsigned cref = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, c.w));
-    same &= __builtin_bit_cast(unsigned, c.w) == cref;
+    const unsigned cref = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, c[0].w));
+#pragma unroll
+    for (int i = 0; i < GPW; ++i)
+        same &= __builtin_bit_cast(unsigned, c[i].w) == cref;
     const float mass_rows = __builtin_bit_cast(float, mref), mass_cols = __builtin_bit_cast(float, cref);
     const bool uniform = LOOP == 0 && a.equal_mass_path && __all(same) && fabsf(mass_rows) <= 3.4e38f && fabsf(mass_cols) <= 3.4e38f;
     const float row_scale = uniform ? mass_cols : 1.f, col_scale = uniform ? mass_rows : 1.f;
 
     float *st = stage_all + wave * kSymStageFloatsPerWave;
-    float3 rsum[kSymRows], csum;  // the wave's sums: its rows over its 64 columns; column `lane` of its group over the 256 rows
-    if constexpr (LOOP == 2) {
-        reinterpret_cast<float4 *>(st)[lane] = c;
-        float ax[kSymRows], ay[kSymRows], az[kSymRows];
+    float *estage = estage_all + (LOOP == 1 ? wave * 128 : 0);
+    float3 csum[GPW];  // column `lane` of the wave's groups over its 256 rows
+    // the rows' sums over the wave's columns: per column of the pair in the packed loops (added when the groups are through)
+    nb_f2 ra[kSymRows][3];
+    float ax[kSymRows], ay[kSymRows], az[kSymRows];
 #pragma unroll
-        for (int k = 0; k < kSymRows; ++k)
-            ax[k] = ay[k] = az[k] = 0.f;
-        float cx = 0.f, cy = 0.f, cz = 0.f;  // accumulators of column (lane + s) mod 64, travelling
-        unsigned off = 16u * (unsigned)lane, addr = 0, cnt;
-        const unsigned base = (unsigned)(size_t)st, mask = 1023u, next_lane = 4u * ((lane + 1) & 63);
-        float eps2 = a.eps2;
-        const float tiny = kGuardMin, pinf = __builtin_inff();
-        asm volatile(SY_GROUP_LOOP(SY_GUARD, SY_POST)
-                     : "+{v53}"(ax[0]), "+{v54}"(ay[0]), "+{v52}"(az[0]), "+{v57}"(ax[1]), "+{v58}"(ay[1]), "+{v56}"(az[1]),
-                       "+{v61}"(ax[2]), "+{v62}"(ay[2]), "+{v60}"(az[2]), "+{v65}"(ax[3]), "+{v66}"(ay[3]), "+{v64}"(az[3]),
-                       "+{v45}"(cx), "+{v68}"(cy), "+{v49}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)
-                     : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]), "{v11}"(eps2),
-                       "{v69}"(tiny), "{v70}"(pinf), "{v10}"(base), "{v55}"(mask), "{v59}"(next_lane)
-                     : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
-                       "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v50", "v51", "scc",
-                       "vcc", "memory");
-        // after 64 rotations lane l holds column l of the group; force on the column body is -m_row * d * inv3
-        csum = make_float3(0.f - cx, 0.f - cy, 0.f - cz);
-#pragma unroll
-        for (int k = 0; k < kSymRows; ++k)
-            rsum[k] = make_float3(ax[k], ay[k], az[k]);
-    } else {
-        // the group as x[128], y[128], z[128], m[128]: the 64 columns twice
-        st[lane] = st[64 + lane] = c.x;
-        st[128 + lane] = st[192 + lane] = c.y;
-        st[256 + lane] = st[320 + lane] = c.z;
-        st[384 + lane] = st[448 + lane] = c.w;
-        float *estage = estage_all + (LOOP == 1 ? wave * 128 : 0);
-        if (LOOP == 1)
-            estage[lane] = estage[64 + lane] = ec * ec;
-        nb_f2 ra[kSymRows][3];
-#pragma unroll
-        for (int k = 0; k < kSymRows; ++k)
-            ra[k][0] = ra[k][1] = ra[k][2] = nb_f2{0.f, 0.f};
-        nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
-        unsigned addr = (unsigned)(size_t)st + 4u * (unsigned)lane, addr_z = addr + 1024u, cnt;
-        const unsigned next_lane = 4u * ((lane + 1) & 63);
-        if constexpr (LOOP == 1) {
-            unsigned addr_e = (unsigned)(size_t)estage + 4u * (unsigned)lane;
-            const nb_f2 e01 = {er[0], er[1]}, e23 = {er[2], er[3]};
-            asm volatile(S11_GROUP_LOOP
-                         : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
-                           "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
-                           "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
-                           "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr),
-                           "+{v86}"(addr_e), [cnt] "=&s"(cnt)
-                         : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
-                           "{v[84:85]}"(e01), "{v[88:89]}"(e23), "{v53}"(next_lane)
-                         : "v2", "v3", "v4", "v5", "v6", "v7", "v10", "v11", "v28", "v29", "v30", "v31", "v32", "v33", "v34",
-                           "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v80", "v81", "v82",
-                           "v83", "scc", "memory");
-        } else if (uniform) {
-            const nb_f2 epsv = {a.eps2, 0.f};
-            asm volatile(S2_GROUP_LOOP
-                         : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
-                           "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
-                           "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
-                           "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), [cnt] "=&s"(cnt)
-                         : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
-                           "{v[8:9]}"(epsv), "{v53}"(next_lane)
-                         : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
-                           "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory");
-        } else {
-            const float eps2 = a.eps2;
-            asm volatile(S3_GROUP_LOOP
-                         : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
-                           "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
-                           "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
-                           "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), [cnt] "=&s"(cnt)
-                         : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
-                           "{v8}"(eps2), "{v53}"(next_lane)
-                         : "v2", "v3", "v4", "v5", "v6", "v7", "v10", "v11", "v28", "v29", "v30", "v31", "v32", "v33", "v34",
-                           "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v80", "v81",
-                           "scc", "memory");
-        }
-        // after 32 steps and rotations the lane holds the first-half sum of column lane + 32 and the second-half sum of column
-        // lane: the two halves of column `lane` meet through one permute
-        const int from = 4 * ((lane + 32) & 63);
-        const float hx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, cx.x)));
-        const float hy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, cy.x)));
-        const float hz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, cz.x)));
-        csum = make_float3((0.f - hx) - cx.y, (0.f - hy) - cy.y, (0.f - hz) - cz.y);
-#pragma unroll
-        for (int k = 0; k < kSymRows; ++k)
-            rsum[k] = make_float3(ra[k][0].x + ra[k][0].y, ra[k][1].x + ra[k][1].y, ra[k][2].x + ra[k][2].y);
+    for (int k = 0; k < kSymRows; ++k) {
+        ra[k][0] = ra[k][1] = ra[k][2] = nb_f2{0.f, 0.f};
+        ax[k] = ay[k] = az[k] = 0.f;
     }
-    if (!diag && gc < a.n_total) {
-        float3 *out = sym_col_slot(a.col_partials, R - a.row_lo / L, sym_distance(R, C, S), S, L);
-        out[wave * 64 + lane] = make_float3(csum.x * col_scale, csum.y * col_scale, csum.z * col_scale);
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        if constexpr (LOOP == 2) {
+            reinterpret_cast<float4 *>(st)[lane] = c[i];
+            float cx = 0.f, cy = 0.f, cz = 0.f;  // accumulators of column (lane + s) mod 64, travelling
+            unsigned off = 16u * (unsigned)lane, addr = 0, cnt;
+            const unsigned base = (unsigned)(size_t)st, mask = 1023u, next_lane = 4u * ((lane + 1) & 63);
+            float eps2 = a.eps2;
+            const float tiny = kGuardMin, pinf = __builtin_inff();
+            asm volatile(SY_GROUP_LOOP(SY_GUARD, SY_POST)
+                         : "+{v53}"(ax[0]), "+{v54}"(ay[0]), "+{v52}"(az[0]), "+{v57}"(ax[1]), "+{v58}"(ay[1]), "+{v56}"(az[1]),
+                           "+{v61}"(ax[2]), "+{v62}"(ay[2]), "+{v60}"(az[2]), "+{v65}"(ax[3]), "+{v66}"(ay[3]), "+{v64}"(az[3]),
+                           "+{v45}"(cx), "+{v68}"(cy), "+{v49}"(cz), "+{v1}"(off), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                         : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]), "{v11}"(eps2),
+                           "{v69}"(tiny), "{v70}"(pinf), "{v10}"(base), "{v55}"(mask), "{v59}"(next_lane)
+                         : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+                           "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v50", "v51", "scc",
+                           "vcc", "memory");
+            // after 64 rotations lane l holds column l of the group; force on the column body is -m_row * d * inv3
+            csum[i] = make_float3(0.f - cx, 0.f - cy, 0.f - cz);
+        } else {
+            // the group as x[128], y[128], z[128], m[128]: the 64 columns twice
+            st[lane] = st[64 + lane] = c[i].x;
+            st[128 + lane] = st[192 + lane] = c[i].y;
+            st[256 + lane] = st[320 + lane] = c[i].z;
+            st[384 + lane] = st[448 + lane] = c[i].w;
+            if (LOOP == 1)
+                estage[lane] = estage[64 + lane] = ec[i] * ec[i];
+            nb_f2 cx = {0.f, 0.f}, cy = cx, cz = cx;  // sums of columns (lane + s) and (lane + s + 32) mod 64, travelling
+            unsigned addr = (unsigned)(size_t)st + 4u * (unsigned)lane, addr_z = addr + 1024u, cnt;
+            const unsigned next_lane = 4u * ((lane + 1) & 63);
+            if constexpr (LOOP == 1) {
+                unsigned addr_e = (unsigned)(size_t)estage + 4u * (unsigned)lane;
+                const nb_f2 e01 = {er[0], er[1]}, e23 = {er[2], er[3]};
+                asm volatile(S11_GROUP_LOOP
+                             : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
+                               "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
+                               "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr),
+                               "+{v86}"(addr_e), [cnt] "=&s"(cnt)
+                             : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
+                               "{v[84:85]}"(e01), "{v[88:89]}"(e23), "{v53}"(next_lane)
+                             : "v2", "v3", "v4", "v5", "v6", "v7", "v10", "v11", "v28", "v29", "v30", "v31", "v32", "v33", "v34",
+                               "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v80", "v81", "v82",
+                               "v83", "scc", "memory");
+            } else if (uniform) {
+                const nb_f2 epsv = {a.eps2, 0.f};
+                asm volatile(S2_GROUP_LOOP
+                             : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
+                               "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
+                               "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                             : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
+                               "{v[8:9]}"(epsv), "{v53}"(next_lane)
+                             : "v2", "v3", "v4", "v5", "v6", "v7", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38",
+                               "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "scc", "memory");
+            } else {
+                const float eps2 = a.eps2;
+                asm volatile(S3_GROUP_LOOP
+                             : "+{v[56:57]}"(ra[0][0]), "+{v[58:59]}"(ra[0][1]), "+{v[60:61]}"(ra[0][2]), "+{v[62:63]}"(ra[1][0]),
+                               "+{v[64:65]}"(ra[1][1]), "+{v[66:67]}"(ra[1][2]), "+{v[68:69]}"(ra[2][0]), "+{v[70:71]}"(ra[2][1]),
+                               "+{v[72:73]}"(ra[2][2]), "+{v[74:75]}"(ra[3][0]), "+{v[76:77]}"(ra[3][1]), "+{v[78:79]}"(ra[3][2]),
+                               "+{v[36:37]}"(cx), "+{v[40:41]}"(cy), "+{v[44:45]}"(cz), "+{v1}"(addr_z), "+{v0}"(addr), [cnt] "=&s"(cnt)
+                             : "{v[12:15]}"(row[0]), "{v[16:19]}"(row[1]), "{v[20:23]}"(row[2]), "{v[24:27]}"(row[3]),
+                               "{v8}"(eps2), "{v53}"(next_lane)
+                             : "v2", "v3", "v4", "v5", "v6", "v7", "v10", "v11", "v28", "v29", "v30", "v31", "v32", "v33", "v34",
+                               "v35", "v38", "v39", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55", "v80", "v81",
+                               "scc", "memory");
+            }
+            // after 32 steps and rotations the lane holds the first-half sum of column lane + 32 and the second-half sum of
+            // column lane: the two halves of column `lane` meet through one permute
+            const int from = 4 * ((lane + 32) & 63);
+            const float hx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, cx.x)));
+            const float hy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, cy.x)));
+            const float hz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, cz.x)));
+            csum[i] = make_float3((0.f - hx) - cx.y, (0.f - hy) - cy.y, (0.f - hz) - cz.y);
+        }
+        csum[i] = make_float3(csum[i].x * col_scale, csum[i].y * col_scale, csum[i].z * col_scale);
+        if (NH == 2 && h == 1 && !diag) {
+            colx[q][i][0][lane] = csum[i].x;
+            colx[q][i][1][lane] = csum[i].y;
+            colx[q][i][2][lane] = csum[i].z;
+        }
     }
 #pragma unroll
     for (int k = 0; k < kSymRows; ++k) {
-        xch[wave][0][k * 64 + lane] = rsum[k].x * row_scale;
-        xch[wave][1][k * 64 + lane] = rsum[k].y * row_scale;
-        xch[wave][2][k * 64 + lane] = rsum[k].z * row_scale;
+        const float3 v = LOOP == 2 ? make_float3(ax[k], ay[k], az[k])
+                                   : make_float3(ra[k][0].x + ra[k][0].y, ra[k][1].x + ra[k][1].y, ra[k][2].x + ra[k][2].y);
+        xch[wave][0][k * 64 + lane] = v.x * row_scale;
+        xch[wave][1][k * 64 + lane] = v.y * row_scale;
+        xch[wave][2][k * 64 + lane] = v.z * row_scale;
     }
-    __syncthreads();
-    const int r = rowbase + tid;  // wave w adds the four waves' sums of rows 64 w ... 64 w + 63, in wave order
+    if (NH == 2)
+        __syncthreads();
+    if (!diag && h == 0) {
+        float3 *out = sym_col_slot(a.col_partials, R - a.row_lo / L, sym_distance(R, C, S), S, L);
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const int cc = (q * GPW + i) * 64 + lane;
+            if (colbase + cc < a.n_total) {
+                float3 v = csum[i];
+                if (NH == 2)
+                    v = make_float3(v.x + colx[q][i][0][lane], v.y + colx[q][i][1][lane], v.z + colx[q][i][2][lane]);
+                out[cc] = v;
+            }
+        }
+    }
+    if (NH == 1)
+        __syncthreads();
+    // thread t adds the four waves' sums of row t of its half, in wave order
+    const int hh = NH == 1 ? 0 : tid >> 8, rr = tid & 255;
+    const int r = R * L + hh * 256 + rr;
     if (r < row_hi) {
         float3 *const row_out = a.row_partials + (size_t)slot * a.row_count;  // P_row[slot][row]
-        row_out[r - a.row_lo] = make_float3(((xch[0][0][tid] + xch[1][0][tid]) + xch[2][0][tid]) + xch[3][0][tid],
-                                            ((xch[0][1][tid] + xch[1][1][tid]) + xch[2][1][tid]) + xch[3][1][tid],
-                                            ((xch[0][2][tid] + xch[1][2][tid]) + xch[2][2][tid]) + xch[3][2][tid]);
+        const int w0 = hh * 4;
+        row_out[r - a.row_lo] = make_float3(((xch[w0][0][rr] + xch[w0 + 1][0][rr]) + xch[w0 + 2][0][rr]) + xch[w0 + 3][0][rr],
+                                            ((xch[w0][1][rr] + xch[w0 + 1][1][rr]) + xch[w0 + 2][1][rr]) + xch[w0 + 3][1][rr],
+                                            ((xch[w0][2][rr] + xch[w0 + 1][2][rr]) + xch[w0 + 2][2][rr]) + xch[w0 + 3][2][rr]);
     }
 }
 
@@ -1577,12 +1610,20 @@ hipError_t launch_forces_symmetric(const SymArgs &a, hipStream_t stream)
     if (sym_quarter_tiles(a.split_len, a.eps2, a.eps_pp, a.packed)) {  // small systems: tiles and diagonal tiles in one launch
         if (a.n_tiles + a.n_diag > 0) {
             const dim3 grid(a.n_tiles + a.n_diag);
-            if (a.eps_pp)
-                hipLaunchKernelGGL(force_sym_quarter_kernel<1>, grid, dim3(256), 0, stream, a);
-            else if (a.eps2 > 0.f)
-                hipLaunchKernelGGL(force_sym_quarter_kernel<0>, grid, dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL(force_sym_quarter_kernel<2>, grid, dim3(256), 0, stream, a);
+            const int loop = a.eps_pp ? 1 : a.eps2 > 0.f ? 0 : 2;
+            if (a.split_len == 256) {
+                if (loop == 1)
+                    hipLaunchKernelGGL((force_sym_quarter_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+                else if (loop == 0)
+                    hipLaunchKernelGGL((force_sym_quarter_kernel<0, 1>), grid, dim3(256), 0, stream, a);
+                else
+                    hipLaunchKernelGGL((force_sym_quarter_kernel<2, 1>), grid, dim3(256), 0, stream, a);
+            } else {  // (sym_quarter_tiles: no per-particle softening here)
+                if (loop == 0)
+                    hipLaunchKernelGGL((force_sym_quarter_kernel<0, 2>), grid, dim3(512), 0, stream, a);
+                else
+                    hipLaunchKernelGGL((force_sym_quarter_kernel<2, 2>), grid, dim3(512), 0, stream, a);
+            }
         }
         return hipGetLastError();
     }

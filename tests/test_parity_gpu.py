@@ -904,14 +904,15 @@ def test_symmetric_mode_matches_oracle_and_one_sided(nb, oracle_mod, n, split_le
     assert rel_state_error(p1, pr) < 1e-6 and rel_state_error(v1, vr) < 1e-6
 
 
-@pytest.mark.parametrize("n", [200, 256, 1000, 5000, 20225])
+@pytest.mark.parametrize("n", [200, 256, 1000, 5000, 20225, 66000])
 def test_small_systems_tile_by_four_waves(nb, oracle_mod, n):
     """Round 4, 256-body splits (every system below 65 536 bodies): a tile is served by four waves, one 64-column group each, the
-    diagonal tiles by the same kernel in the same launch (force_sym_quarter_kernel).  Each WAVE decides whether its rows and its
-    64 columns carry one mass: body sets whose species change inside a split, inside a 64-column group and on their boundaries;
+    diagonal tiles by the same kernel in the same launch (force_sym_quarter_kernel); 512-body splits (below 131 072 bodies; n =
+    66 000 here): eight waves, two groups each.  Each WAVE decides whether its rows and its columns carry one mass: body sets whose species change inside a split, inside a 64-column group and on their boundaries;
     massless bodies; coincident bodies; eps = 0 (the guarded loop) and per-particle softening (their own loops); all against the
     fp64 truth and the one-sided kernels, the equal-mass path on and off, and two shards = one context, bit for bit."""
     rng = np.random.default_rng(n)
+    L = nb.pair_once_split_len(n)                                                    # 256, or 512 from 65 536 bodies
     pos, vel = nb.plummer(n, seed=500 + n)
     cases = {"equal": pos.copy()}
     sp = pos.copy()
@@ -931,7 +932,7 @@ def test_small_systems_tile_by_four_waves(nb, oracle_mod, n):
                 continue
             acc = {}
             for mode, on in (("pair_once", True), ("pair_once", False), ("one_sided", True)):
-                with nb.NBodySystem(n, split_len=256) as s:
+                with nb.NBodySystem(n, split_len=L) as s:
                     s.set_force_mode(mode)
                     s.set_equal_mass_path(on)
                     if pps:
@@ -955,7 +956,7 @@ def test_small_systems_tile_by_four_waves(nb, oracle_mod, n):
     state = cases["species"]
     runs = []
     for graph in (0, 1):
-        with nb.NBodySystem(n, split_len=256) as s:
+        with nb.NBodySystem(n, split_len=L) as s:
             s.set_force_mode("pair_once")
             s.set_graph_replay(graph)
             s.setParticlesPosition(state)
@@ -965,14 +966,14 @@ def test_small_systems_tile_by_four_waves(nb, oracle_mod, n):
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     if n >= 4096:
         from n_body_problem_amd.multi import MultiGpuSystem
-        with MultiGpuSystem(n, devices=[0, 0], force_mode="pair_once", transport="peer_copy", split_len=256) as m:
+        with MultiGpuSystem(n, devices=[0, 0], force_mode="pair_once", transport="peer_copy", split_len=L) as m:
             m.set_state(state, vel)
             m.step_n(5, 1e-3, 1e-2)
             got = m.download()
             n_padded = m.n_padded
         pp, vv = np.zeros((n_padded, 4), np.float32), np.zeros((n_padded, 4), np.float32)
         pp[:n], vv[:n] = state, vel
-        with nb.NBodySystem(n_padded, split_len=256) as s:
+        with nb.NBodySystem(n_padded, split_len=L) as s:
             s.set_force_mode("pair_once")
             s.setParticlesPosition(pp)
             s.setParticlesVelocity(vv)
