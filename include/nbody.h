@@ -153,8 +153,10 @@ int nbody_step(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw
 int nbody_step_async(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, const float *d_masses,
                      float dt, float softening);
 int nbody_step_n(nbody_ctx *ctx, int k, float dt, float softening); /* k steps on the owned buffers, one sync */
-/* The same on caller-owned device buffers.  Where the loop is launch-bound -- measured: the pair-once mode up to 32 768
- * bodies; the launches of a one-sided step are faster enqueued eagerly at every size -- ONE step is captured from the stream into a HIP graph after an eager first step and replayed k - 1 times: the
+/* The same on caller-owned device buffers.  Where the loop is launch-bound -- measured: a pair-once step of several launches on
+ * two streams (per-particle softening with softening = 0, the A/B arrangements of nbody_set_rows_per_lane) up to 32 768
+ * bodies; the launches of a one-sided step, and since round 4 the two kernels of a pair-once step with 256- or 512-body splits,
+ * are faster enqueued eagerly at every size -- ONE step is captured from the stream into a HIP graph after an eager first step and replayed k - 1 times: the
  * same kernels, arguments and order, hence the same bits.  nbody_set_graph_replay: -1 automatic (that rule), 0 never,
  * 1 always. */
 int nbody_step_n_on(nbody_ctx *ctx, float *d_positions_xyzm, float *d_velocities_xyzw, int k, float dt, float softening);

@@ -121,6 +121,15 @@ static int fail(nbody_ctx *c, int status, const std::string &msg)
 
 static void free_sym_tiles(nbody_ctx *c);
 
+// SymArgs::packed of the context's rows-per-lane setting (nbody_set_rows_per_lane)
+static int sym_packed(const nbody_ctx *c)
+{
+    int packed = c->rows_per_lane == 4 ? 1 : c->rows_per_lane == 2 ? 2 : c->rows_per_lane == 1 ? 0 : 3;
+    if (packed >= 2 && !c->equal_mass_path)
+        packed = 3;  // no tile can take the equal-mass loop
+    return packed;
+}
+
 // Partial sums consumed or forgotten: the next force call starts a new step (and recomputes the equal-mass flags).
 static void clear_split_done(nbody_ctx *c)
 {
@@ -1295,9 +1304,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         // (164.0 against 176.2 ms with the four-row loop, profiles/r03_ab_general_mass_eight_rows.txt).  The other arrangements
         // stay reachable through nbody_set_rows_per_lane for A/B measurement in one process: 2 = round 2's (equal-mass tiles eight
         // rows in a four-waves kernel, the others four rows), 4 = four rows per lane everywhere, 1 = the one-column loops.
-        sa.packed = c->rows_per_lane == 4 ? 1 : c->rows_per_lane == 2 ? 2 : c->rows_per_lane == 1 ? 0 : 3;
-        if (sa.packed >= 2 && !c->equal_mass_path)
-            sa.packed = 3;  // no tile can take the equal-mass loop
+        sa.packed = sym_packed(c);
         sa.equal_mass_path = c->equal_mass_path ? 1 : 0;
         const bool quarter = sym_quarter_tiles(L, sa.eps2, sa.eps_pp, sa.packed);  // small systems: no flags, no diagonal launch
         auto part_args = [&](const nbody_ctx::SymPart &p) {
@@ -1328,9 +1335,16 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
         // part's tile launch is over, its column-side sums per group and the row-side sums of its rows.  With two slots the
         // diagonal tiles of part p + 2 follow the sums of part p on this stream, and the tile launch of part p + 2 waits for
         // them (they ran beside part p + 1's tiles).
-        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        // (small systems, one part: the tile launch serves the diagonal tiles and nothing runs beside it -- no fork, no join:
+        // an eagerly enqueued step at N = 1024 took 29 us with them against 18.5 us replayed as a graph)
+        const bool aux_idle = quarter && K == 1;
+        if (!aux_idle) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        }
         auto diag_launch = [&](int p) -> int {
+            if (aux_idle)
+                return NBODY_OK;
             part_args(plan.parts[(size_t)p]);
             TimedLaunch t(c, &c->ev_aux, &c->aux_ms, &c->aux_launches, c->aux_stream, true);  // reported separately
             HIP_TRY(c, launch_forces_symmetric_diag(sa, c->aux_stream));
@@ -1382,8 +1396,10 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 if (int rc = diag_launch(p + 2))
                     return rc;
         }
-        HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (!aux_idle) {
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
         c->pending = &plan.parts.back();
         for (int s = 0; s < c->n_splits; ++s)
             if ((s >= first && s < first + count) != complement)
@@ -1657,7 +1673,7 @@ int nbody_step(nbody_ctx *c, float *d_pos, float *d_vel, const float *d_masses, 
 // enqueued back to back, so the one-sided step (flags, forces, update) is FASTER eager at every size (N = 256: 29 against
 // 40 us per step; N = 20 225: 143 against 153); the pair-once step is seven launches on two streams with events between
 // them, and there the replay wins up to a few ten thousand bodies (N = 4096: 96 against 114 us; N = 20 225: 169 against
-// 190; N = 65 536: 801 against 788).  Automatic = pair-once mode and at most this many bodies.
+// 190; N = 65 536: 801 against 788).  Automatic = pair-once mode, at most this many bodies, and a step of more than two kernels.
 constexpr int64_t kGraphAutoBodies = 32768;
 
 int nbody_set_graph_replay(nbody_ctx *c, int mode)
@@ -1687,8 +1703,13 @@ int nbody_step_n_on(nbody_ctx *c, float *d_pos, float *d_vel, int k, float dt, f
     if (!c || k < 0)
         return fail(c, NBODY_ERR_INVALID, "nbody_step_n: bad argument");
     const bool whole = c->row_lo == 0 && c->row_count == c->n_total;
+    // (round 4: where the tile launch serves the diagonal tiles too -- sym_quarter_tiles, one part -- a pair-once step is two
+    // kernels on one stream, and those are faster enqueued eagerly as well: N = 1024: 12.5 against 18.5 us per step, 20 225:
+    // 85.9 against 91.4, profiles/r04_pair_once_small_n.txt)
+    const bool two_kernels = c->force_mode == NBODY_FORCE_SYMMETRIC && c->sum_parts <= 1 &&
+                             sym_quarter_tiles((int)c->split_len, softening * softening, c->eps_pp, sym_packed(c));
     const bool want = c->graph_replay == 1 || (c->graph_replay == -1 && c->force_mode == NBODY_FORCE_SYMMETRIC &&
-                                               c->n_total <= kGraphAutoBodies);
+                                               c->n_total <= kGraphAutoBodies && !two_kernels);
     const bool use_graph = want && whole && !c->timing && k >= 3 && c->n_total > 0;
     int s = 0;
     if (use_graph) {

@@ -260,7 +260,7 @@ class NBodySystem:
         check(self._lib.nbody_set_strip_len(self._ctx, int(length)), self._ctx)
 
     def set_graph_replay(self, mode: int) -> None:
-        """-1: automatic (pair-once mode up to 32 768 bodies, where the replay measured faster), 0: never, 1: always."""
+        """-1: automatic (a pair-once step of more than two kernels up to 32 768 bodies, where the replay measured faster), 0: never, 1: always."""
         check(self._lib.nbody_set_graph_replay(self._ctx, int(mode)), self._ctx)
 
     def forces(self, col_lo: int, col_count: int, softening: float, positions=None) -> None:
