@@ -121,6 +121,16 @@ static int fail(nbody_ctx *c, int status, const std::string &msg)
 
 static void free_sym_tiles(nbody_ctx *c);
 
+// Small and mid-size pair-once systems (every row, the tiles in one part, nothing summed yet, up to 320 splits of single tiles):
+// ONE finishing kernel forms the column sums, the row sums and their combination and ends in the update / the half kick.
+static bool sym_fused_finish(const nbody_ctx *c)
+{
+    constexpr int fused_max_splits = 320;
+    return c->force_mode == NBODY_FORCE_SYMMETRIC && c->row_lo == 0 && c->row_count == c->n_total && c->pending &&
+           !c->sym_reduced && !c->sym_rows_summed && c->pending->g1 - c->pending->g0 == c->group_count &&
+           c->pending->row_off == 0 && c->pending->col_off == 0 && c->n_splits <= fused_max_splits && c->strip_len == 1;
+}
+
 // SymArgs::packed of the context's rows-per-lane setting (nbody_set_rows_per_lane)
 static int sym_packed(const nbody_ctx *c)
 {
@@ -1483,10 +1493,7 @@ int nbody_update(nbody_ctx *c, float *d_pos, float *d_vel, float dt)
         // Small and mid-size systems (every row, the tiles in one part, nothing summed yet): one finishing kernel instead of
         // column sums + row sums + update (up to 320 splits: -4 % per step at N = 32 768, nothing from 131 072 on,
         // profiles/r03_ab_fused_finish.txt; the bits are the same either way).
-        constexpr int fused_max_splits = 320;
-        if (c->force_mode == NBODY_FORCE_SYMMETRIC && c->row_lo == 0 && c->row_count == c->n_total && c->pending &&
-            !c->sym_reduced && !c->sym_rows_summed && c->pending->g1 - c->pending->g0 == c->group_count &&
-            c->pending->row_off == 0 && c->pending->col_off == 0 && c->n_splits <= fused_max_splits && c->strip_len == 1) {
+        if (sym_fused_finish(c)) {
             int rc = all_splits_done(c, "nbody_update");
             if (rc != NBODY_OK)
                 return rc;
@@ -1562,6 +1569,19 @@ int nbody_kdk_prepare(nbody_ctx *c)
         c->acc_valid = true;
         return NBODY_OK;
     }
+    if (sym_fused_finish(c)) {  // one kernel instead of column sums + row sums + combination + copy (the same bits)
+        int rc = all_splits_done(c, "nbody_kdk_prepare");
+        if (rc == NBODY_OK)
+            rc = ensure_acc(c);
+        if (rc != NBODY_OK)
+            return rc;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, launch_sym_finish_kick(reinterpret_cast<const float3 *>(c->partials), c->col_partials, c->acc, nullptr,
+                                          (int)c->n_total, (int)c->split_len, c->n_splits, c->group_splits, 0.f, false, c->stream));
+        clear_split_done(c);
+        c->acc_valid = true;
+        return NBODY_OK;
+    }
     const float4 *partials;
     int n_splits;
     int rc = summed_partials(c, "nbody_kdk_prepare", &partials, &n_splits);
@@ -1612,13 +1632,22 @@ int nbody_kdk_kick(nbody_ctx *c, float *d_vel, float dt)
     HIP_TRY(c, hipSetDevice(c->device));
     {
         TimedLaunch t(c, &c->ev_update, &c->update_ms, &c->update_launches);
-        const float4 *partials;
-        int n_splits;
-        rc = summed_partials(c, "nbody_kdk_kick", &partials, &n_splits);
-        if (rc != NBODY_OK)
-            return rc;
-        HIP_TRY(c, launch_kdk_kick(reinterpret_cast<float4 *>(d_vel), c->acc, partials, (int)c->row_count, n_splits, dt,
-                                   c->stream));
+        if (sym_fused_finish(c)) {
+            rc = all_splits_done(c, "nbody_kdk_kick");
+            if (rc != NBODY_OK)
+                return rc;
+            HIP_TRY(c, launch_sym_finish_kick(reinterpret_cast<const float3 *>(c->partials), c->col_partials, c->acc,
+                                              reinterpret_cast<float4 *>(d_vel), (int)c->n_total, (int)c->split_len, c->n_splits,
+                                              c->group_splits, dt, true, c->stream));
+        } else {
+            const float4 *partials;
+            int n_splits;
+            rc = summed_partials(c, "nbody_kdk_kick", &partials, &n_splits);
+            if (rc != NBODY_OK)
+                return rc;
+            HIP_TRY(c, launch_kdk_kick(reinterpret_cast<float4 *>(d_vel), c->acc, partials, (int)c->row_count, n_splits, dt,
+                                       c->stream));
+        }
     }
     clear_split_done(c);
     c->acc_valid = true;
@@ -1706,7 +1735,7 @@ int nbody_step_n_on(nbody_ctx *c, float *d_pos, float *d_vel, int k, float dt, f
     // (round 4: where the tile launch serves the diagonal tiles too -- sym_quarter_tiles, one part -- a pair-once step is two
     // kernels on one stream, and those are faster enqueued eagerly as well: N = 1024: 12.5 against 18.5 us per step, 20 225:
     // 85.9 against 91.4, profiles/r04_pair_once_small_n.txt)
-    const bool two_kernels = c->force_mode == NBODY_FORCE_SYMMETRIC && c->sum_parts <= 1 &&
+    const bool two_kernels = c->force_mode == NBODY_FORCE_SYMMETRIC && c->sum_parts <= 1 &&  // (kick-drift-kick: three, fused finish)
                              sym_quarter_tiles((int)c->split_len, softening * softening, c->eps_pp, sym_packed(c));
     const bool want = c->graph_replay == 1 || (c->graph_replay == -1 && c->force_mode == NBODY_FORCE_SYMMETRIC &&
                                                c->n_total <= kGraphAutoBodies && !two_kernels);

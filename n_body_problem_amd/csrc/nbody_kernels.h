@@ -131,6 +131,10 @@ hipError_t launch_sym_combine(const float4 *rowsum, const float4 *colparts, floa
 // association as the three kernels above).
 hipError_t launch_sym_finish_update(const float3 *row_partials, const float3 *col_partials, float4 *pos_all, float4 *vel_rows,
                                     int n_total, int split_len, int n_splits, int group_splits, float dt, hipStream_t stream);
+// The same sums ending in kick-drift-kick's closing half kick (kick) or in the accelerations alone: acc[b] as launch_sym_combine
+// leaves it and kdk_kick_kernel copies it.
+hipError_t launch_sym_finish_kick(const float3 *row_partials, const float3 *col_partials, float4 *acc, float4 *vel_rows, int n_total,
+                                  int split_len, int n_splits, int group_splits, float dt, bool kick, hipStream_t stream);
 
 // Partial accelerations of rows [row_lo,row_lo+row_count) from splits [split_first, split_first+split_count).
 // rows_per_lane in {1,2,4,8}.  eps2 == 0 selects the zero-distance-guarded variant.

@@ -1771,6 +1771,9 @@ __global__ __launch_bounds__(kTile) void sym_combine_kernel(const float4 *rowsum
 // combination and the kick-drift of update_kernel in one launch instead of three -- one lane per (body, group), the eight
 // group values of a body combined in ascending order through LDS: the same sums in the same association, not a bit changes.
 // At N = 32 768 the tile kernel takes 185 us of a 234 us step and the rest is small launches (profiles/r03_mid_range_kernel_stats.txt).
+// MODE 0: kick-drift (update_kernel); 1: the closing half kick of kick-drift-kick, the acceleration kept (kdk_kick_kernel<1>);
+// 2: the acceleration only (kdk_kick_kernel<0>) -- pos_all is then the acceleration array.
+template <int MODE>
 __global__ __launch_bounds__(256) void sym_finish_update_kernel(const float3 *row_partials, const float3 *col_partials,
                                                                 float4 *pos_all, float4 *vel_rows, int n_total, int split_len,
                                                                 int n_splits, int group_splits, int n_groups, float dt)
@@ -1838,6 +1841,18 @@ __global__ __launch_bounds__(256) void sym_finish_update_kernel(const float3 *ro
         ay += part[k][bl][1];
         az += part[k][bl][2];
     }
+    if (MODE != 0) {
+        pos_all[b] = make_float4(ax, ay, az, 0.f);  // sym_combine_kernel's entry, which kdk_kick_kernel copies
+        if (MODE == 1) {
+            float4 v = vel_rows[b];
+            const double hh = 0.5 * (double)dt;
+            v.x = (float)__builtin_fma((double)ax, hh, (double)v.x);
+            v.y = (float)__builtin_fma((double)ay, hh, (double)v.y);
+            v.z = (float)__builtin_fma((double)az, hh, (double)v.z);
+            vel_rows[b] = v;
+        }
+        return;
+    }
     float4 v = vel_rows[b];
     float4 x = pos_all[b];
     const double h = (double)dt;
@@ -1857,8 +1872,23 @@ hipError_t launch_sym_finish_update(const float3 *row_partials, const float3 *co
     if (n_total <= 0)
         return hipSuccess;
     const int n_groups = (n_splits + group_splits - 1) / group_splits;
-    hipLaunchKernelGGL(sym_finish_update_kernel, dim3((n_total + 31) / 32), dim3(256), 0, stream, row_partials, col_partials, pos_all,
+    hipLaunchKernelGGL(sym_finish_update_kernel<0>, dim3((n_total + 31) / 32), dim3(256), 0, stream, row_partials, col_partials, pos_all,
                        vel_rows, n_total, split_len, n_splits, group_splits, n_groups, dt);
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_finish_kick(const float3 *row_partials, const float3 *col_partials, float4 *acc, float4 *vel_rows, int n_total,
+                                  int split_len, int n_splits, int group_splits, float dt, bool kick, hipStream_t stream)
+{
+    if (n_total <= 0)
+        return hipSuccess;
+    const int n_groups = (n_splits + group_splits - 1) / group_splits;
+    if (kick)
+        hipLaunchKernelGGL(sym_finish_update_kernel<1>, dim3((n_total + 31) / 32), dim3(256), 0, stream, row_partials, col_partials,
+                           acc, vel_rows, n_total, split_len, n_splits, group_splits, n_groups, dt);
+    else
+        hipLaunchKernelGGL(sym_finish_update_kernel<2>, dim3((n_total + 31) / 32), dim3(256), 0, stream, row_partials, col_partials,
+                           acc, nullptr, n_total, split_len, n_splits, group_splits, n_groups, 0.f);
     return hipGetLastError();
 }
 
