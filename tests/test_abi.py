@@ -42,6 +42,16 @@ def test_abi_version_and_status_strings(lib):
         assert lib.nbody_status_string(s) not in (b"ok", b"unknown status")
 
 
+def test_header_constants_match_the_python_mirror():
+    """The crossover of NBODY_FORCE_AUTO and the number of summation groups are part of the ABI's contract: the host mirror must
+    not drift from the header."""
+    from n_body_problem_amd import system as nb
+    text = open(os.path.join(ROOT, "include", "nbody.h")).read()
+    defines = dict(re.findall(r"^#define\s+(NBODY_[A-Z_]+)\s+(\d+)\s*$", text, flags=re.M))
+    assert int(defines["NBODY_PAIR_ONCE_MIN_BODIES"]) == nb.PAIR_ONCE_MIN_BODIES == 0     # round 4: pair-once at every size
+    assert int(defines["NBODY_SYM_GROUPS"]) == 8
+
+
 def test_default_split_len_is_tile_aligned_and_sharding_independent(lib):
     for n in (1, 255, 256, 257, 1024, 8192, 65536, 1 << 20, (1 << 22) + 1):
         s = lib.nbody_default_split_len(n)
