@@ -1198,11 +1198,13 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                                 if (cnt > 0)
                                     per_xcd[(size_t)k % per_xcd.size()].push_back(make_int4(R, C0, cnt, sym_row_slot(R, C0, S, SL)));
                             }
-                // whole strips first, the shorter ones of the band's edges behind them (the launch's tail is made of short
-                // workgroups) -- inside each XCD's sequence, so that a block's strips keep meeting in one L2 (a partition of the
-                // interleaved list shifted the launch slots: 4.6 instead of 1.4 GB of fabric reads per N = 2^20 pass)
+                // whole strips first, the shorter ones of the band's edges behind them, longest first (the launch's tail is made
+                // of ever shorter workgroups: three-tile strips, then two, then one -- 145.4 against 145.9 ms per N = 2^20 step
+                // with the short ones in list order, profiles/r04_strips_ab.txt) -- inside each XCD's sequence, so that a block's
+                // strips keep meeting in one L2 (a partition of the interleaved list shifted the launch slots: 4.6 instead of 1.4 GB
+                // of fabric reads per N = 2^20 pass)
                 for (auto &seq : per_xcd)
-                    std::stable_partition(seq.begin(), seq.end(), [&](const int4 &t) { return t.z == SL; });
+                    std::stable_sort(seq.begin(), seq.end(), [](const int4 &x, const int4 &y) { return x.z > y.z; });
                 for (size_t j = 0, more = 1; more; ++j) {
                     more = 0;
                     for (auto &seq : per_xcd)
