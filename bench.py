@@ -121,13 +121,16 @@ def reference_size_leg(nb):
 
 def executed_pairs(mode, n, split_len, rows_here):
     """Pair evaluations the TIMED force launches of rank 0 execute per step.  Pair-once mode: the S (S - 1) / 2 tiles of two
-    different splits; the S diagonal tiles (0.1 % of the pairs) run in their own kernel on the auxiliary stream, are not in
-    `force_ms` and therefore not counted here either."""
+    different splits, and the S diagonal tiles where the tile launch serves them (as full squares: every ordered pair of the
+    split, 0.4 % of the launch's evaluations at N = 2^20); elsewhere they run in their own kernel on the auxiliary stream, are
+    not in `force_ms` and therefore not counted here either."""
     if mode == "one_sided":
         return rows_here * n
     S = -(-n // split_len)
     tiles = S * (S - 1) / 2
-    if split_len == 256:   # small systems: the tile launch serves the diagonal tiles too, as full squares (force_sym_quarter_kernel)
+    # the tile launch serves the diagonal tiles too, as full squares that keep their row side: small systems
+    # (force_sym_quarter_kernel) and, since round 4, strips (2048-body splits, a split count that is a multiple of 32)
+    if split_len in (256, 512) or (split_len == 2048 and S % 32 == 0):
         tiles += S
     return tiles * split_len * split_len * rows_here / n
 

@@ -1175,6 +1175,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
             // distance d has column split (R + d) mod S.  Blocks of 8 row splits x 8 distances touch 23 splits' bodies
             // instead of 128; workgroups are dealt round-robin to the 8 XCDs (MI355X_MICROARCH.md), so block k's tiles
             // take the launch slots congruent to k mod 8 and meet in one XCD's L2.
+            constexpr int kDiagInTilesMinStrip = 1;  // strips longer than this carry the diagonal tiles in the tile launch
             const int B = 8;
             auto list_rows = [&](int r_lo, int r_hi) {  // the strips with a row split in [r_lo, r_hi), in launch order
                 std::vector<int4> tiles;
@@ -1198,6 +1199,13 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                                 if (cnt > 0)
                                     per_xcd[(size_t)k % per_xcd.size()].push_back(make_int4(R, C0, cnt, sym_row_slot(R, C0, S, SL)));
                             }
+                // Strips: the DIAGONAL tiles ride in the tile launch, as full squares of the hand-scheduled loops that keep their
+                // row side (slot 0) -- 512 one-tile workgroups more for the launch's tail at N = 2^20 instead of a compiler-scheduled
+                // launch beside it (0.4 % more pair evaluations; profiles/r04_strips_ab.txt)
+                if (SL > kDiagInTilesMinStrip)
+                    for (int R = r_lo; R < r_hi; ++R)
+                        if (selected(R))
+                            per_xcd[(size_t)R % per_xcd.size()].push_back(make_int4(R, R, 1, 0));
                 // whole strips first, the shorter ones of the band's edges behind them, longest first (the launch's tail is made
                 // of ever shorter workgroups: three-tile strips, then two, then one -- 145.4 against 145.9 ms per N = 2^20 step
                 // with the short ones in list order, profiles/r04_strips_ab.txt) -- inside each XCD's sequence, so that a block's
@@ -1272,7 +1280,7 @@ static int forces_impl(nbody_ctx *c, const float *d_pos, int64_t col_lo, int64_t
                 }
                 std::vector<int4> tiles = list_rows(part.split_lo, part.split_hi);
                 std::vector<int2> diag;
-                for (int R = part.split_lo; R < part.split_hi; ++R)
+                for (int R = part.split_lo; R < part.split_hi && SL <= kDiagInTilesMinStrip; ++R)
                     if (selected(R))
                         diag.push_back(make_int2(R, R));
                 HIP_TRY(c, hipSetDevice(c->device));

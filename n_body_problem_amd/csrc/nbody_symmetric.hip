@@ -701,9 +701,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(ROWS8 ==
     __syncthreads();
     // the tile's column sums out of LDS -- P_col[R][d - 1][.] -- and LDS cleared for the next tile of the strip
     auto write_columns = [&](const Tile tl) {
-        float3 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, tl.C, S), S, L);
+        // (a DIAGONAL tile in the list -- strips: the plan puts them into the tile launch, as full squares -- keeps its row side only:
+        // every ordered pair of the split has been met, the column side holds the same forces a second time)
+        const bool keep = tl.C != t.x;
+        float3 *out = sym_col_slot(a.col_partials, t.x - a.row_lo / L, keep ? sym_distance(t.x, tl.C, S) : 1, S, L);
         for (int c = tid; c < L; c += kSymThreads) {
-            if (tl.colbase + c < a.n_total)
+            if (keep && tl.colbase + c < a.n_total)
                 out[c] = make_float3(lds.sx[c] * tl.col_scale, lds.sy[c] * tl.col_scale, lds.sz[c] * tl.col_scale);
             if (MODE != 0)
                 lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
@@ -1514,11 +1517,12 @@ __global__ __launch_bounds__(64 * W) void force_sym_general_kernel(SymArgs a)
     }
 
     // DIAG: both sides of the split, P_row[0][b]; else the tile's column sums, P_col[R][d-1][.], and LDS cleared for the next tile
+    const bool keep = DIAG || C != t.x;  // a diagonal tile in the TILE list (strips): a full square, the row side only
     float3 *out = DIAG ? a.row_partials + (rowbase - a.row_lo)
-                       : sym_col_slot(a.col_partials, t.x - a.row_lo / L, sym_distance(t.x, C, S), S, L);
+                       : sym_col_slot(a.col_partials, t.x - a.row_lo / L, keep ? sym_distance(t.x, C, S) : 1, S, L);
     const int col_hi = DIAG ? row_hi : a.n_total;  // a diagonal tile's columns are the context's own rows
     for (int c = tid; c < L; c += kSymThreads) {
-        if (colbase + c < col_hi)
+        if (keep && colbase + c < col_hi)
             out[c] = make_float3(lds.sx[c], lds.sy[c], lds.sz[c]);
         lds.sx[c] = lds.sy[c] = lds.sz[c] = 0.f;
     }
