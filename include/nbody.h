@@ -316,14 +316,17 @@ int nbody_set_equal_mass_path(nbody_ctx *ctx, int on);
  * for several launches, shards and column-range calls always take one part.  nbody_set_early_summation(on) is
  * nbody_set_summation_parts(on ? 0 : 1). */
 int nbody_set_summation_parts(nbody_ctx *ctx, int parts);
-/* Strips (pair-once mode, round 4).  With 2048-body splits (N >= 2^20) and a number of splits that is a multiple of 8 x 4, a
- * tile workgroup takes four consecutive column splits of its row split and keeps the rows' sums in registers across them: a
- * quarter of the row-side partial sums (N = 2^20: 4.0 instead of 6.4 GB of partial sums per pass, held in ONE launch -- the
- * automatic summation parts then take one part).  The blocks of four are absolute, so a strip never straddles a summation
- * group or a rank's column chunk: the state stays bit-identical for 1, 2, 4 or 8 contexts sharing the rows; against single
- * tiles the results differ by rounding (one chain per row over a strip's columns instead of a sum of four).  Column ranges
- * given to nbody_forces must then start and end on multiples of the strip length.  len: 0 = automatic (that rule), 1 = single
- * tiles everywhere, 2, 4, 8 = that many splits where the split count allows it (A/B measurement, tests). */
+/* Strips (pair-once mode, round 4).  With 2048-body splits (N >= 2^20) and a number of splits that is a multiple of 8 x K, a
+ * tile workgroup takes K consecutive column splits of its row split and keeps the rows' sums in registers across them: 1 / K
+ * of the row-side partial sums, and the whole pass of N = 2^20 held in ONE launch (the automatic summation parts then take one
+ * part).  Automatic: K = 4 from 1024 splits on (N >= 2^21: a quarter of the row side), K = 2 below (N = 2^20: 4.8 instead of
+ * 6.4 GB of partial sums per pass) -- a strip is one workgroup, and with strips of four a rank of eight's share of an N = 2^20
+ * pass is 5.3 rounds of 3.5 ms workgroups: 21.6 ms against 20.0 with strips of two and 18.7 with single tiles, while one GPU
+ * runs both strip lengths equally fast.  The blocks of K are absolute, so a strip never straddles a summation group or a
+ * rank's column chunk: the state stays bit-identical for 1, 2, 4 or 8 contexts sharing the rows; against single tiles the
+ * results differ by rounding (one chain per row over a strip's columns instead of a sum of K).  Column ranges given to
+ * nbody_forces must then start and end on multiples of the strip length.  len: 0 = automatic (that rule), 1 = single tiles
+ * everywhere, 2, 4, 8 = that many splits where the split count allows it (A/B measurement, tests). */
 int nbody_set_strip_len(nbody_ctx *ctx, int len);
 int nbody_set_early_summation(nbody_ctx *ctx, int on);
 /* Bytes of partial-sum arrays the context holds at the moment (they are allocated by the first force call and only grow). */

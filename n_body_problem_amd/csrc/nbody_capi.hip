@@ -819,9 +819,14 @@ int nbody_set_force_mode(nbody_ctx *c, int mode)
 // takes a workgroup that owns a whole CU, measured 7 % slower: profiles/r04_ab_whole_cu_workgroup.txt).  The blocks of four are
 // absolute and the number of splits must be a multiple of 8 x 4, so no strip straddles a summation group or a rank's column
 // chunk and which sums exist stays a function of (n_total, split_len) alone; other split counts keep single tiles.
+// Automatic: strips of FOUR column splits from 1024 splits on (N >= 2^21), of TWO below (N = 2^20).  A strip is one workgroup, and
+// a rank of eight's share of an N = 2^20 pass is only 4088 strips of four on 768 workgroup slots -- 5.3 rounds of 3.5 ms, six in
+// practice: 21.6 ms against 18.7 ms with single tiles and 20.0 ms with strips of two, while one GPU runs strips of two and of
+// four equally fast (146.2 ms; profiles/r04_shard_rate.txt).  A function of (n_total, split_len) only, like the split length:
+// the strips define the order of the row-side sums.
 static int sym_strip_len(const nbody_ctx *c)
 {
-    const int want = c->strip_setting ? c->strip_setting : (c->split_len >= 2048 ? 4 : 1);
+    const int want = c->strip_setting ? c->strip_setting : (c->split_len >= 2048 ? (c->n_splits >= 1024 ? 4 : 2) : 1);
     return want > 1 && c->n_splits % (kSymGroups * want) == 0 && c->split_len == 2048 ? want : 1;
 }
 

@@ -713,7 +713,7 @@ def test_strips_keep_the_rows_sums_in_registers_and_the_results(nb, oracle_mod, 
              "pps, arbitrary masses": {"pps": eps_pp, "masses": random_masses}, "eps = 0": {"eps": 0.0},
              "four-row loops": {"rpl": 4}, "pps, eps = 0": {"pps": eps_pp, "eps": 0.0}}
     for name, kw in cases.items():
-        a4, held4 = accel(0, **kw)
+        a4, held4 = accel(4, **kw)                                # strips of four (automatic from 1024 splits on)
         a1, held1 = accel(1, **kw)
         p = pos.copy()
         if "masses" in kw:
@@ -727,15 +727,20 @@ def test_strips_keep_the_rows_sums_in_registers_and_the_results(nb, oracle_mod, 
         net = (m[:, None] * a4).sum(0)
         assert np.all(np.abs(net) < 1e-5 * (m[:, None] * np.abs(a4)).sum(0)), name
         assert held4 < 0.7 * held1, (name, held4, held1)          # rows: a quarter; columns: what they were
-    base, _ = accel(0)
+    base, _ = accel(4)
     for parts in (1, 2, 4, 8):
-        assert np.array_equal(accel(0, parts=parts)[0], base), parts
+        assert np.array_equal(accel(4, parts=parts)[0], base), parts
+    # the automatic strip length below 1024 splits is two (a rank of eight's share of the pass keeps short workgroups)
+    a2, held2 = accel(2)
+    auto, held_auto = accel(0)
+    assert np.array_equal(auto, a2) and held_auto == held2 and held2 < 0.85 * accel(1)[1]   # 32 splits: 16 + 11 slots against 16 + 17
+    assert np.linalg.norm(a2 - base) / np.linalg.norm(base) < 1e-6
     with nb.NBodySystem(n, split_len=2048) as s:
         s.set_force_mode("pair_once")
         s.setParticlesPosition(pos)
         s.setParticlesVelocity(vel)
         with pytest.raises(nb.NBodyError):
-            s.forces(0, 2 * 2048, 1e-3)                              # two of a strip's four column splits
+            s.forces(0, 3 * 2048, 1e-3)                              # one and a half strips of two column splits
 
 
 def test_summation_parts_api(nb):

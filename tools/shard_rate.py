@@ -17,6 +17,7 @@ ap.add_argument("--rank", type=int, default=3)
 ap.add_argument("--mode", default="pair_once")
 ap.add_argument("--split-len", type=int, nargs="*", default=[2048, 1024])
 ap.add_argument("--two-streams", action="store_true")
+ap.add_argument("--strip-len", type=int, default=0, help="pair-once: nbody_set_strip_len (0 = the library's rule)")
 ap.add_argument("--morton", action="store_true", help="the bodies along the Morton curve (what bench.py's default layout gives every rank)")
 args = ap.parse_args()
 n = args.bodies
@@ -31,6 +32,8 @@ for L in args.split_len:
     lo = args.rank * chunk
     s = nb.NBodySystem(n, row_lo=lo, row_count=chunk, split_len=L)
     s.set_force_mode(args.mode)
+    if args.mode == "pair_once":
+        s.set_strip_len(args.strip_len)
     s.setParticlesPosition(pos)
     s.setParticlesVelocity(vel[lo:lo + chunk])
     side = torch.cuda.Stream()
@@ -54,7 +57,7 @@ for L in args.split_len:
         torch.cuda.synchronize()
         if it:
             best = min(best, ev[0].elapsed_time(ev[1]))
-    print(f"N={n} rank {args.rank}/{args.world} mode={args.mode} split_len={L} two_streams={args.two_streams} morton={args.morton}: "
+    print(f"N={n} rank {args.rank}/{args.world} mode={args.mode} split_len={L} strip_len={args.strip_len} two_streams={args.two_streams} morton={args.morton}: "
           f"{best:.3f} ms per step share -> x{args.world} ranks = {float(n) * n / best / 1e9:.3f}e12 interactions/s")
     if args.morton:
         # one rank's share of a layout refresh (nbody_multi_reorder without the wire): the permutation from the rank's own replica,
